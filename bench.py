@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- random-action rollout throughput of the MapEnv.step() hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch: every env of the batch advances one tick
+(device-drawn uniform random actions, as rollout.py:62-70), i.e. ONE launch of the fused
+kernel that moves agents, resolves conflicts, fires beams, respawns apples / waste, writes the
+uint8 observations [E,N,15,15,3], rewards and dones.  Inputs (all env state) are resident in
+HBM when the timed region starts; `horizon` auto-resets are inside the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--game harvest|cleanup] [--envs E]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL); envs are sharded by global
+index with no data-path collective (weak scaling: --envs is per GPU).  `--gather` adds the
+optional RCCL all-gather of obs/rew over xGMI after every step.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch (SURVEY.md
+8d: bytes/env-step x envs per launch) / average launch duration measured with HIP events on
+the launch stream over the timed region.  `cpu_baseline` = the C oracle (a port of the
+reference algorithm, oracle/ssd_oracle.c) timed on this host, one core, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s achievable
+HORIZON = 1000               # run_scripts/train_baseline.py:131
+
+
+def cpu_baseline(game, amap, n_agents, target_s=12.0):
+    """The oracle on one host core over a bounded sample of the same workload."""
+    from oracle import pyoracle
+    from sequential_social_dilemma_games_amd import config
+    E = 512
+    o = pyoracle.Oracle(game, amap, E, n_agents, config.make_lut(), seed=0)
+    o.reset()
+    for _ in range(3):
+        o.step_random()
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < target_s:
+        for _ in range(10):
+            o.step_random()
+        steps += 10
+    dt = time.perf_counter() - t0
+    return {"value": E * n_agents * steps / dt, "unit": "agent-env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d envs x %d steps (%.1f s), oracle/ssd_oracle.c single thread; the Python reference itself "
+                      "measured 2289 agent-env-steps/s per core in the build container (BASELINE.md)" % (E, steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--game", default="harvest", choices=["harvest", "cleanup", "harvest25x38", "cleanup48x36"])
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--agents", type=int, default=None)
+    ap.add_argument("--gather", action="store_true", help="RCCL all-gather of obs/rew after every step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from sequential_social_dilemma_games_amd import constants as K
+    from sequential_social_dilemma_games_amd.engine import VecEngine
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    game, amap, n_agents = {
+        "harvest": (K.GAME_HARVEST, K.HARVEST_MAP, 5),
+        "cleanup": (K.GAME_CLEANUP, K.CLEANUP_MAP, 5),
+        "harvest25x38": (K.GAME_HARVEST, K.harvest_map_25x38(), 5),
+        "cleanup48x36": (K.GAME_CLEANUP, K.cleanup_map_48x36(), 10),
+    }[args.game]
+    if args.agents is not None:
+        n_agents = args.agents
+    E = args.envs
+    eng = VecEngine(game, amap, num_envs=E, num_agents=n_agents, seed=0, env_index_base=rank * E, device=local_rank)
+    out = eng.alloc_outputs()
+    gathered = None
+    if args.gather and dist is not None:
+        gathered = (torch.empty((world,) + tuple(out[0].shape), dtype=torch.uint8, device=out[0].device),
+                    torch.empty((world,) + tuple(out[1].shape), dtype=torch.int32, device=out[1].device))
+
+    def one_step(k):
+        if k % HORIZON == 0:
+            eng.reset(obs=out[0])
+        eng.step_random(out=out)
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered[0], out[0])
+            dist.all_gather_into_tensor(gathered[1], out[1])
+
+    for k in range(args.warmup):
+        one_step(k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                                   # torch's current stream == the stream the kernels are launched on
+    for k in range(args.steps):
+        one_step(args.warmup + k)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if eng.status() != 0:
+        raise SystemExit("device status word is non-zero")
+    if dist is not None:
+        tw = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(tw[0]), float(tw[1])
+
+    if rank == 0:
+        total_agent_steps = float(E) * n_agents * args.steps * world
+        value = total_agent_steps / wall
+        bytes_env = eng.algorithmic_bytes_per_env_step()
+        launch_us = dev_ms * 1e3 / args.steps      # average launch-to-launch duration of the step kernel on its stream
+        achieved = bytes_env * E / (launch_us * 1e-6) / 1e9
+        res = {
+            "metric": "agent-env-steps/sec (random actions)", "value": value, "unit": "agent-env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s %dx%d, %d agents, %d envs per GPU, uniform random actions, reset every %d steps"
+                                   % (args.game, eng.H, eng.W, n_agents, E, HORIZON),
+                       "envs_per_gpu": E, "agents": n_agents, "obs": "uint8 [E,N,15,15,3]", "launches_per_step": 1,
+                       "gather": bool(gathered is not None), "parallelism": "env-shard x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "ssd_env_kernel<%d>" % game, "bytes_per_env_step": bytes_env,
+                         "avg_launch_us": launch_us},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(game, amap, n_agents)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,130 @@
+/* include/ssd.h -- C ABI of libssd_hip.so, the MI355X-native engine for the
+ * MapEnv.step() hot path of the Harvest / Cleanup gridworlds.
+ *
+ * The reference is pure Python: it has no FFI.  The boundary this ABI replaces is the
+ * RLlib MultiAgentEnv duck type that `MapEnv` implements (reference
+ * social_dilemmas/envs/map_env.py:60,152,214) -- every entry point below cites the
+ * reference method it stands in for.  The host-side mirror of that interface
+ * (sequential_social_dilemma_games_amd/map_env.py) binds these symbols through ctypes;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions: every call returns 0 on success or a negative SSD_E_* code and never
+ * throws; the caller owns every buffer passed in (the engine only allocates its own
+ * state); one handle = one device + one caller-chosen stream per call; calls on one
+ * handle are not re-entrant, distinct handles are independent; there is no global state
+ * (the reference's module-global RNGs become per-handle seed + counters).  There is no
+ * CPU backend: without a usable HIP device ssd_create fails with SSD_E_DEVICE.
+ *
+ * Batched layouts (E = num_envs of the handle, N = num_agents, V = 2*view_len+1):
+ *   actions i32 [E,N]   -1 = agent absent from the action dict this step
+ *   order   u8  [E,N]   agent indices in action-dict order, 0xFF-terminated; NULL = index order
+ *   obs     u8  [E,N,V,V,3]   RGB; the reference's float64 obs is (u8 - 128.0) / 255.0
+ *   rew     i32 [E,N]
+ *   done    u8  [E,N]   always 0 (agent.py:174-175,209-210)
+ */
+#ifndef SSD_H
+#define SSD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSD_ABI_VERSION 1
+
+enum {
+    SSD_OK = 0,
+    SSD_E_INVALID = -1,   /* bad argument / configuration (open map, too many agents, ...) */
+    SSD_E_DEVICE = -2,    /* no usable HIP device, or a HIP call failed (see ssd_last_error) */
+    SSD_E_NOMEM = -3,
+    SSD_E_STATE = -4      /* device status word is non-zero (see ssd_device_status) */
+};
+
+enum { SSD_GAME_HARVEST = 0, SSD_GAME_CLEANUP = 1 };
+
+/* flags of the stepping calls */
+enum {
+    SSD_HOST_PTRS = 1u << 0, /* actions/order/obs/rew/done are host memory: the engine stages them
+                                and the call returns after the results have landed.  Without it
+                                they are device pointers on the handle's device and the call only
+                                enqueues work on `stream`. */
+    SSD_NO_ROTATE = 1u << 1  /* ssd_observe only: reset-form observation (map_env.py:239-240) */
+};
+
+/* bits of the device status word */
+enum {
+    SSD_ST_BAD_ACTION = 1u << 0,  /* action id outside the game's Discrete(n): KeyError in agent.action_map */
+    SSD_ST_NO_SPAWN = 1u << 1,    /* not enough spawn points (assert at map_env.py:661) */
+    SSD_ST_MOVE_LOOKUP = 1u << 2  /* agent_by_pos lookup miss (would be a KeyError at map_env.py:506) */
+};
+
+typedef struct ssd_env ssd_env;
+
+typedef struct ssd_config {
+    uint32_t struct_size;        /* sizeof(ssd_config), for ABI evolution */
+    int32_t game;                /* SSD_GAME_*: HarvestEnv (harvest.py:18) or CleanupEnv (cleanup.py:30) */
+    int32_t height, width;       /* ascii_map shape (map_env.py:132-150) */
+    const char *base_map;        /* height*width ASCII bytes, row-major, wall-closed */
+    int32_t num_envs;            /* E: independent env copies held by this handle */
+    int32_t num_agents;          /* N (ctor arg num_agents, map_env.py:62); 0..64 */
+    int32_t view_len;            /* HARVEST_VIEW_SIZE / CLEANUP_VIEW_SIZE = 7 (harvest.py:15, cleanup.py:22) */
+    int32_t beam_len;            /* ACTIONS['FIRE'] = ACTIONS['CLEAN'] = 5 (harvest.py:11, cleanup.py:11-12) */
+    uint64_t seed;               /* replaces np.random.seed / random.seed */
+    uint32_t env_index_base;     /* global index of env 0 of this handle (multi-GPU shards) */
+    int32_t device_id;           /* HIP device ordinal */
+    int32_t keep_beams;          /* 1: persist the beam overlay (map_env.py:86 beam_pos) between steps so that
+                                    ssd_get_state / ssd_observe / ssd_render_full see it; 0: beams live only
+                                    inside the step that draws them (they are already in that step's obs) */
+    const uint8_t *color_lut;    /* 128*3 glyph -> RGB (map_env.py:24-41, cleanup.py:15-18); NULL = defaults */
+    /* rand < p thresholds as ceil(p * 2^32); NULL = derived from the reference constants */
+    const uint64_t *harvest_thresholds;        /* [4]  SPAWN_PROB[min(n,3)] (harvest.py:13,100) */
+    const uint64_t *cleanup_apple_thresholds;  /* [potential_waste_area+1], index = current #'H' (cleanup.py:156-171) */
+    const uint64_t *cleanup_waste_thresholds;  /* same indexing */
+} ssd_config;
+
+/* MapEnv.__init__ (map_env.py:62-102) + HarvestEnv/CleanupEnv.__init__ (harvest.py:20-28, cleanup.py:32-66)
+ * for E env copies.  Unlike the reference constructor it does not spawn agents: call ssd_reset first. */
+int ssd_create(const ssd_config *cfg, ssd_env **out);
+int ssd_destroy(ssd_env *env);
+
+/* MapEnv.reset (map_env.py:214-249) on the envs selected by env_mask (u8 [E], NULL = all; same memory
+ * kind as obs).  obs may be NULL. */
+int ssd_reset(ssd_env *env, const uint8_t *env_mask, uint8_t *obs, uint32_t flags, void *stream);
+
+/* MapEnv.step (map_env.py:152-212) on every env.  obs / rew / done may be NULL. */
+int ssd_step(ssd_env *env, const int32_t *actions, const uint8_t *order, uint8_t *obs, int32_t *rew,
+             uint8_t *done, uint32_t flags, void *stream);
+
+/* The random-action rollout step of rollout.py:62-70: actions are drawn on the device, uniformly over
+ * Discrete(num_actions), from the ACTION stream; actions_out (i32 [E,N]) may be NULL. */
+int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, uint8_t *obs, int32_t *rew,
+                    uint8_t *done, uint32_t flags, void *stream);
+
+/* Observation of the current state without stepping (the per-agent part of map_env.py:189-199). */
+int ssd_observe(ssd_env *env, uint8_t *obs, uint32_t flags, void *stream);
+
+/* State access (host pointers, synchronous; any pointer may be NULL).  Mirrors what the reference's tests
+ * poke directly: world_map (map_env.py:85), beam_pos (:86), Agent.pos / .orientation (agent.py:37-38).
+ *   world, beam: i8 [E,H,W] ASCII (beam: 0 = none; needs keep_beams)   pos: i16 [E,N,2] (row, col)
+ *   orient: u8 [E,N] 0 LEFT 1 RIGHT 2 UP 3 DOWN (key order of ORIENTATIONS, map_env.py:19-22)
+ *   episode, t: u32 [E] PRNG coordinates (resets so far - 1, steps since reset) */
+int ssd_get_state(ssd_env *env, int8_t *world, int8_t *beam, int16_t *pos, uint8_t *orient,
+                  uint32_t *episode, uint32_t *t);
+int ssd_set_state(ssd_env *env, const int8_t *world, const int8_t *beam, const int16_t *pos,
+                  const uint8_t *orient, const uint32_t *episode, const uint32_t *t);
+
+/* MapEnv.map_to_colors() on the full grid of env e (map_env.py:316-339): rgb u8 [H,W,3], host pointer. */
+int ssd_render_full(ssd_env *env, int32_t e, uint8_t *rgb);
+
+/* Queries. */
+int ssd_potential_waste_area(const ssd_env *env);             /* cleanup.py:36-38 */
+int ssd_device_status(ssd_env *env, uint32_t *status, int clear); /* synchronises the handle's device work */
+int ssd_synchronize(ssd_env *env);
+const char *ssd_last_error(const ssd_env *env);               /* NULL env: error of the last failed ssd_create */
+int ssd_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,78 @@
+"""ctypes binding of libssd_hip.so (the C ABI declared in include/ssd.h).
+
+There is no fallback: if the shared library is missing or cannot be loaded this module
+raises, and every product entry point (engine, envs, bench) fails with it.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libssd_hip.so")
+
+SSD_OK, SSD_E_INVALID, SSD_E_DEVICE, SSD_E_NOMEM, SSD_E_STATE = 0, -1, -2, -3, -4
+SSD_HOST_PTRS, SSD_NO_ROTATE = 1, 2
+SSD_ST_BAD_ACTION, SSD_ST_NO_SPAWN, SSD_ST_MOVE_LOOKUP = 1, 2, 4
+ABI_VERSION = 1
+
+# every symbol include/ssd.h declares
+SYMBOLS = ("ssd_create", "ssd_destroy", "ssd_reset", "ssd_step", "ssd_step_random", "ssd_observe",
+           "ssd_get_state", "ssd_set_state", "ssd_render_full", "ssd_potential_waste_area",
+           "ssd_device_status", "ssd_synchronize", "ssd_last_error", "ssd_abi_version")
+
+
+class SsdConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("game", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+                ("base_map", C.c_char_p), ("num_envs", C.c_int32), ("num_agents", C.c_int32),
+                ("view_len", C.c_int32), ("beam_len", C.c_int32), ("seed", C.c_uint64),
+                ("env_index_base", C.c_uint32), ("device_id", C.c_int32), ("keep_beams", C.c_int32),
+                ("color_lut", C.c_void_p), ("harvest_thresholds", C.c_void_p),
+                ("cleanup_apple_thresholds", C.c_void_p), ("cleanup_waste_thresholds", C.c_void_p)]
+
+
+class SsdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises SsdError when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SsdError("HIP extension missing: %s (build it with `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` or `make -C sequential_social_dilemma_games_amd/csrc`); there is no CPU "
+                           "fallback" % LIB_PATH)
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as exc:
+            raise SsdError("cannot load %s: %s (no CPU fallback)" % (LIB_PATH, exc))
+        vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
+        L.ssd_create.argtypes = [C.POINTER(SsdConfig), C.POINTER(vp)]
+        L.ssd_destroy.argtypes = [vp]
+        L.ssd_reset.argtypes = [vp, vp, vp, u32, vp]
+        L.ssd_step.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp]
+        L.ssd_step_random.argtypes = [vp, i32, vp, vp, vp, vp, u32, vp]
+        L.ssd_observe.argtypes = [vp, vp, u32, vp]
+        L.ssd_get_state.argtypes = [vp] + [vp] * 6
+        L.ssd_set_state.argtypes = [vp] + [vp] * 6
+        L.ssd_render_full.argtypes = [vp, i32, vp]
+        L.ssd_potential_waste_area.argtypes = [vp]
+        L.ssd_device_status.argtypes = [vp, C.POINTER(u32), C.c_int]
+        L.ssd_synchronize.argtypes = [vp]
+        L.ssd_last_error.argtypes = [vp]
+        L.ssd_last_error.restype = C.c_char_p
+        L.ssd_abi_version.argtypes = []
+        for name in SYMBOLS:
+            getattr(L, name)
+        if L.ssd_abi_version() != ABI_VERSION:
+            raise SsdError("libssd_hip.so ABI %d != expected %d: rebuild" % (L.ssd_abi_version(), ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def check(rc, handle=None):
+    if rc != SSD_OK:
+        msg = lib().ssd_last_error(handle)
+        raise SsdError("libssd_hip call failed (%d): %s" % (rc, msg.decode() if msg else "?"))

@@ -1,0 +1,435 @@
+// csrc/ssd_capi.hip -- host side of the C ABI declared in include/ssd.h.
+// Owns the engine state in HBM (hipMalloc), derives the static per-map tables, stages host
+// buffers when asked to, and launches the fused kernel of ssd_kernels.hip.  No CPU compute
+// path exists here: every stepping call ends in a kernel launch or an error code.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ssd.h"
+#include "ssd_internal.hpp"
+
+using ssd::Params;
+
+static thread_local std::string g_create_error;
+
+struct ssd_env {
+    int game = 0, H = 0, W = 0, S = 0, E = 0, N = 0, view_len = 7, V = 15, beam_len = 5;
+    int device = 0, keep_beams = 0, potential_waste = 0;
+    uint64_t seed = 0;
+    uint32_t env_base = 0;
+    Params p{};                       // persistent part of the kernel parameters
+    std::vector<void *> allocs;
+    // staging for SSD_HOST_PTRS
+    int32_t *st_actions = nullptr, *st_rew = nullptr, *st_actions_out = nullptr;
+    uint8_t *st_order = nullptr, *st_obs = nullptr, *st_done = nullptr, *st_mask = nullptr, *st_rgb = nullptr;
+    std::string err;
+};
+
+namespace {
+
+#define SSD_HIP(env, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (env)->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+            return SSD_E_DEVICE;                                                                \
+        }                                                                                       \
+    } while (0)
+
+// rand < p  <=>  k < ceil(p * 2^32) for rand = k / 2^32
+uint64_t threshold(double p) {
+    if (p <= 0.0) return 0;
+    const double x = std::ceil(p * 4294967296.0);
+    return x >= 4294967296.0 ? 4294967296ull : (uint64_t)x;
+}
+
+// cleanup.py:156-171 compute_probabilities for a map holding n_h cells of 'H' (constants :24-27)
+void cleanup_probs(int potential, int n_h, double *p_apple, double *p_waste) {
+    const double depletion = 0.4, restoration = 0.0, waste_p = 0.5, apple_p = 0.05;
+    double density = 0;
+    if (potential > 0) density = 1 - (double)(potential - n_h) / (double)potential;
+    if (density >= depletion) { *p_apple = 0; *p_waste = 0; return; }
+    *p_waste = waste_p;
+    *p_apple = density <= restoration ? apple_p : (1 - (density - restoration) / (depletion - restoration)) * apple_p;
+}
+
+uint32_t magic(uint32_t d) { return d ? (uint32_t)(4294967296ull / d) + 1u : 0u; }
+
+template <typename T>
+int dev_alloc(ssd_env *env, T **out, size_t count, bool zero = true) {
+    void *ptr = nullptr;
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    hipError_t e = hipMalloc(&ptr, bytes);
+    if (e != hipSuccess) { env->err = std::string("hipMalloc: ") + hipGetErrorString(e); return SSD_E_NOMEM; }
+    if (zero) {
+        e = hipMemset(ptr, 0, bytes);
+        if (e != hipSuccess) { env->err = std::string("hipMemset: ") + hipGetErrorString(e); return SSD_E_DEVICE; }
+    }
+    env->allocs.push_back(ptr);
+    *out = static_cast<T *>(ptr);
+    return SSD_OK;
+}
+
+template <typename T>
+int upload(ssd_env *env, T **out, const std::vector<T> &host) {
+    int rc = dev_alloc(env, out, host.size(), host.empty());
+    if (rc) return rc;
+    if (!host.empty()) SSD_HIP(env, hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SSD_OK;
+}
+
+int fail_create(const std::string &msg, int code) {
+    g_create_error = msg;
+    return code;
+}
+
+size_t obs_bytes(const ssd_env *env) { return (size_t)env->E * env->N * env->V * env->V * 3; }
+
+int ensure_staging(ssd_env *env) {
+    if (env->st_obs) return SSD_OK;
+    const size_t en = (size_t)env->E * env->N;
+    int rc;
+    if ((rc = dev_alloc(env, &env->st_actions, en))) return rc;
+    if ((rc = dev_alloc(env, &env->st_actions_out, en))) return rc;
+    if ((rc = dev_alloc(env, &env->st_rew, en))) return rc;
+    if ((rc = dev_alloc(env, &env->st_order, en))) return rc;
+    if ((rc = dev_alloc(env, &env->st_done, en))) return rc;
+    if ((rc = dev_alloc(env, &env->st_mask, (size_t)env->E))) return rc;
+    if ((rc = dev_alloc(env, &env->st_obs, obs_bytes(env)))) return rc;
+    return SSD_OK;
+}
+
+// Runs one launch of the fused kernel with the per-call pointers filled in; handles host staging.
+int run(ssd_env *env, int mode, const int32_t *actions, const uint8_t *order, const uint8_t *mask,
+        int num_actions_random, int32_t *actions_out, uint8_t *obs, int32_t *rew, uint8_t *done, int rotate,
+        uint32_t flags, void *stream) {
+    SSD_HIP(env, hipSetDevice(env->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t en = (size_t)env->E * env->N;
+    const bool host = (flags & SSD_HOST_PTRS) != 0;
+    Params p = env->p;
+    p.mode = mode; p.rotate = rotate; p.num_actions_random = num_actions_random;
+    if (!host) {
+        if (obs && (reinterpret_cast<uintptr_t>(obs) & 3u)) { env->err = "obs must be 4-byte aligned"; return SSD_E_INVALID; }
+        p.actions = actions; p.order = order; p.mask = mask; p.actions_out = actions_out;
+        p.obs = obs; p.rew = rew; p.done = done;
+        ssd::launch(p, env->game, stream);
+        SSD_HIP(env, hipGetLastError());
+        return SSD_OK;
+    }
+    int rc = ensure_staging(env);
+    if (rc) return rc;
+    if (actions) { SSD_HIP(env, hipMemcpyAsync(env->st_actions, actions, en * sizeof(int32_t), hipMemcpyHostToDevice, s)); p.actions = env->st_actions; }
+    if (order) { SSD_HIP(env, hipMemcpyAsync(env->st_order, order, en, hipMemcpyHostToDevice, s)); p.order = env->st_order; }
+    if (mask) { SSD_HIP(env, hipMemcpyAsync(env->st_mask, mask, (size_t)env->E, hipMemcpyHostToDevice, s)); p.mask = env->st_mask; }
+    if (actions_out) p.actions_out = env->st_actions_out;
+    if (obs) {
+        p.obs = env->st_obs;
+        if (mask)   // rows of envs that are not reset must come back unchanged
+            SSD_HIP(env, hipMemcpyAsync(env->st_obs, obs, obs_bytes(env), hipMemcpyHostToDevice, s));
+    }
+    if (rew) p.rew = env->st_rew;
+    if (done) p.done = env->st_done;
+    ssd::launch(p, env->game, stream);
+    SSD_HIP(env, hipGetLastError());
+    if (actions_out) SSD_HIP(env, hipMemcpyAsync(actions_out, env->st_actions_out, en * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (obs) SSD_HIP(env, hipMemcpyAsync(obs, env->st_obs, obs_bytes(env), hipMemcpyDeviceToHost, s));
+    if (rew) SSD_HIP(env, hipMemcpyAsync(rew, env->st_rew, en * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (done) SSD_HIP(env, hipMemcpyAsync(done, env->st_done, en, hipMemcpyDeviceToHost, s));
+    SSD_HIP(env, hipStreamSynchronize(s));
+    return SSD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssd_abi_version(void) { return SSD_ABI_VERSION; }
+
+const char *ssd_last_error(const ssd_env *env) { return env ? env->err.c_str() : g_create_error.c_str(); }
+
+int ssd_create(const ssd_config *cfg, ssd_env **out) {
+    if (!cfg || !out) return fail_create("null argument", SSD_E_INVALID);
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(ssd_config)) return fail_create("ssd_config.struct_size mismatch", SSD_E_INVALID);
+    const int H = cfg->height, W = cfg->width, N = cfg->num_agents, E = cfg->num_envs;
+    const int V = 2 * cfg->view_len + 1;
+    if (cfg->game != SSD_GAME_HARVEST && cfg->game != SSD_GAME_CLEANUP) return fail_create("unknown game", SSD_E_INVALID);
+    if (!cfg->base_map || H < 3 || W < 3 || H > 4095 || W > 4095 || (long)H * W > ssd::kMaxCells)
+        return fail_create("map must be 3..4095 on a side with at most 4096 cells", SSD_E_INVALID);
+    if (E < 1 || N < 0 || N > ssd::kMaxAgents) return fail_create("need num_envs >= 1 and 0 <= num_agents <= 64", SSD_E_INVALID);
+    if (cfg->view_len < 0 || (long)N * V * V > 16383) return fail_create("num_agents * (2*view_len+1)^2 must be <= 16383", SSD_E_INVALID);
+    if (cfg->beam_len < 0 || cfg->beam_len > ssd::kMaxBeamLen) return fail_create("beam_len must be 0..21", SSD_E_INVALID);
+    const int hw = H * W;
+    // Appendix C.11 of SURVEY.md: the reference indexes out of range on maps without a closed wall
+    // border (agent.py:111); the engine rejects them.
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            const char ch = cfg->base_map[r * W + c];
+            if ((r == 0 || c == 0 || r == H - 1 || c == W - 1) && ch != '@') return fail_create("map border must be all '@'", SSD_E_INVALID);
+            if (ch <= 0) return fail_create("map cells must be 7-bit ASCII", SSD_E_INVALID);
+        }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail_create("no HIP device available: this engine has no CPU path", SSD_E_DEVICE);
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail_create("device_id out of range", SSD_E_INVALID);
+    if (hipSetDevice(cfg->device_id) != hipSuccess) return fail_create("hipSetDevice failed", SSD_E_DEVICE);
+
+    ssd_env *env = new ssd_env();
+    env->game = cfg->game; env->H = H; env->W = W; env->E = E; env->N = N;
+    env->view_len = cfg->view_len; env->V = V; env->beam_len = cfg->beam_len;
+    env->device = cfg->device_id; env->keep_beams = cfg->keep_beams ? 1 : 0;
+    env->seed = cfg->seed; env->env_base = cfg->env_index_base;
+    const int S = (hw + 15) & ~15;
+    env->S = S;
+
+    // static per-map tables (map_env.py:93-101, harvest.py:22-26, cleanup.py:44-62)
+    std::vector<uint8_t> cellinfo(S, 0), reset_world(S, 0);
+    std::vector<uint16_t> spawn_cells;
+    const char apple_ch = cfg->game == SSD_GAME_HARVEST ? 'A' : 'B';
+    for (int c = 0; c < hw; ++c) {
+        const char b = cfg->base_map[c];
+        if (b == apple_ch) cellinfo[c] |= ssd::kInfoApple;
+        if (cfg->game == SSD_GAME_CLEANUP && (b == 'H' || b == 'R')) { cellinfo[c] |= ssd::kInfoWaste; env->potential_waste++; }
+        if (b == 'P') spawn_cells.push_back((uint16_t)c);
+        char w = ' ';                         // reset_map (:560-564) + custom_reset (harvest.py:57-60, cleanup.py:84-92)
+        if (b == '@') w = '@';
+        else if (cfg->game == SSD_GAME_HARVEST && b == 'A') w = 'A';
+        else if (cfg->game == SSD_GAME_CLEANUP && (b == 'H' || b == 'R' || b == 'S')) w = b;
+        reset_world[c] = (uint8_t)w;
+    }
+    std::vector<uint32_t> lut(128, 0);
+    if (cfg->color_lut) {
+        for (int i = 0; i < 128; ++i)
+            lut[i] = cfg->color_lut[3 * i] | (cfg->color_lut[3 * i + 1] << 8) | (cfg->color_lut[3 * i + 2] << 16);
+    } else {                                  // map_env.py:24-41 DEFAULT_COLOURS + cleanup.py:15-18 CLEANUP_COLORS
+        auto set = [&](char ch, int r, int g, int b) { lut[(int)ch] = r | (g << 8) | (b << 16); };
+        set('@', 180, 180, 180); set('A', 0, 255, 0); set('F', 255, 255, 0); set('P', 159, 67, 255);
+        set('1', 159, 67, 255); set('2', 2, 81, 154); set('3', 204, 0, 204); set('4', 216, 30, 54);
+        set('5', 254, 151, 0); set('6', 100, 255, 255); set('7', 99, 99, 255); set('8', 250, 204, 255);
+        set('9', 238, 223, 16); set('C', 100, 255, 255); set('S', 113, 75, 24); set('H', 99, 156, 194);
+        set('R', 113, 75, 24);
+    }
+    const int n_thr = env->potential_waste + 1;
+    std::vector<uint64_t> thr_ca(n_thr), thr_cw(n_thr);
+    for (int n = 0; n < n_thr; ++n) {
+        if (cfg->cleanup_apple_thresholds && cfg->cleanup_waste_thresholds) {
+            thr_ca[n] = cfg->cleanup_apple_thresholds[n]; thr_cw[n] = cfg->cleanup_waste_thresholds[n];
+        } else {
+            double pa, pw;
+            cleanup_probs(env->potential_waste, n, &pa, &pw);
+            thr_ca[n] = threshold(pa); thr_cw[n] = threshold(pw);
+        }
+    }
+
+    Params &p = env->p;
+    p.E = E; p.N = N; p.H = H; p.W = W; p.S = S;
+    p.view_len = cfg->view_len; p.V = V; p.beam_len = cfg->beam_len;
+    p.keep_beams = env->keep_beams;
+    p.w_magic = magic((uint32_t)W);
+    p.per_env_magic = magic((uint32_t)(N * V * V)); p.vv_magic = magic((uint32_t)(V * V)); p.v_magic = magic((uint32_t)V);
+    p.seed_lo = (uint32_t)cfg->seed; p.seed_hi = (uint32_t)(cfg->seed >> 32); p.env_base = cfg->env_index_base;
+    p.n_spawn = (int)spawn_cells.size(); p.n_thr = n_thr;
+    const double sp[4] = {0, 0.005, 0.02, 0.05};   // harvest.py:13 SPAWN_PROB
+    for (int i = 0; i < 4; ++i) p.thr_h[i] = cfg->harvest_thresholds ? cfg->harvest_thresholds[i] : threshold(sp[i]);
+
+    auto bail = [&](int rc) {
+        g_create_error = env->err;
+        for (void *ptr : env->allocs) (void)hipFree(ptr);
+        delete env;
+        return rc;
+    };
+    int rc;
+    if (ssd::lds_bytes(S) > 64 * 1024) { env->err = "map too large for the 64 KiB LDS budget"; return bail(SSD_E_INVALID); }
+    if ((rc = dev_alloc(env, &p.world, (size_t)E * S))) return bail(rc);
+    if (env->keep_beams) { if ((rc = dev_alloc(env, &p.beam, (size_t)E * S))) return bail(rc); }
+    if ((rc = dev_alloc(env, &p.agents, (size_t)E * N))) return bail(rc);
+    if ((rc = dev_alloc(env, &p.status, 1))) return bail(rc);
+    {   // header: episode = 0xFFFFFFFF ("never reset"; the first reset wraps it to 0)
+        std::vector<uint4> hdr(E);
+        for (int e = 0; e < E; ++e) hdr[e] = make_uint4(0, 0, 0xFFFFFFFFu, 0);
+        if ((rc = upload(env, &p.hdr, hdr))) return bail(rc);
+        std::vector<uint8_t> w0((size_t)E * S, 0);   // world starts blank (map_env.py:85), pads stay 0
+        for (int e = 0; e < E; ++e) std::memset(w0.data() + (size_t)e * S, ' ', hw);
+        if (hipMemcpy(p.world, w0.data(), w0.size(), hipMemcpyHostToDevice) != hipSuccess) { env->err = "hipMemcpy(world)"; return bail(SSD_E_DEVICE); }
+    }
+    uint8_t *d8; uint16_t *d16; uint32_t *d32; uint64_t *d64;
+    if ((rc = upload(env, &d8, cellinfo))) return bail(rc);
+    p.cellinfo = d8;
+    if ((rc = upload(env, &d8, reset_world))) return bail(rc);
+    p.reset_world = d8;
+    if ((rc = upload(env, &d16, spawn_cells))) return bail(rc);
+    p.spawn_cells = d16;
+    if ((rc = upload(env, &d32, lut))) return bail(rc);
+    p.lut = d32;
+    if ((rc = upload(env, &d64, thr_ca))) return bail(rc);
+    p.thr_ca = d64;
+    if ((rc = upload(env, &d64, thr_cw))) return bail(rc);
+    p.thr_cw = d64;
+    *out = env;
+    return SSD_OK;
+}
+
+int ssd_destroy(ssd_env *env) {
+    if (!env) return SSD_E_INVALID;
+    (void)hipSetDevice(env->device);
+    (void)hipDeviceSynchronize();
+    for (void *ptr : env->allocs) (void)hipFree(ptr);
+    delete env;
+    return SSD_OK;
+}
+
+int ssd_reset(ssd_env *env, const uint8_t *env_mask, uint8_t *obs, uint32_t flags, void *stream) {
+    if (!env) return SSD_E_INVALID;
+    return run(env, ssd::kModeReset, nullptr, nullptr, env_mask, 0, nullptr, obs, nullptr, nullptr, /*rotate=*/0, flags, stream);
+}
+
+int ssd_step(ssd_env *env, const int32_t *actions, const uint8_t *order, uint8_t *obs, int32_t *rew, uint8_t *done,
+             uint32_t flags, void *stream) {
+    if (!env || !actions) { if (env) env->err = "actions is null"; return SSD_E_INVALID; }
+    return run(env, ssd::kModeStep, actions, order, nullptr, 0, nullptr, obs, rew, done, 1, flags, stream);
+}
+
+int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, uint8_t *obs, int32_t *rew, uint8_t *done,
+                    uint32_t flags, void *stream) {
+    if (!env) return SSD_E_INVALID;
+    const int na = env->game == SSD_GAME_HARVEST ? 8 : 9;
+    if (num_actions < 1 || num_actions > na) { env->err = "num_actions outside the game's Discrete(n)"; return SSD_E_INVALID; }
+    return run(env, ssd::kModeStep, nullptr, nullptr, nullptr, num_actions, actions_out, obs, rew, done, 1, flags, stream);
+}
+
+int ssd_observe(ssd_env *env, uint8_t *obs, uint32_t flags, void *stream) {
+    if (!env || !obs) return SSD_E_INVALID;
+    return run(env, ssd::kModeObserve, nullptr, nullptr, nullptr, 0, nullptr, obs, nullptr, nullptr,
+               (flags & SSD_NO_ROTATE) ? 0 : 1, flags, stream);
+}
+
+int ssd_get_state(ssd_env *env, int8_t *world, int8_t *beam, int16_t *pos, uint8_t *orient, uint32_t *episode, uint32_t *t) {
+    if (!env) return SSD_E_INVALID;
+    SSD_HIP(env, hipSetDevice(env->device));
+    SSD_HIP(env, hipDeviceSynchronize());
+    const int E = env->E, N = env->N, S = env->S, hw = env->H * env->W, W = env->W;
+    if (world || beam) {
+        std::vector<uint8_t> buf((size_t)E * S);
+        if (world) {
+            SSD_HIP(env, hipMemcpy(buf.data(), env->p.world, buf.size(), hipMemcpyDeviceToHost));
+            for (int e = 0; e < E; ++e) std::memcpy(world + (size_t)e * hw, buf.data() + (size_t)e * S, hw);
+        }
+        if (beam) {
+            if (!env->keep_beams) { env->err = "beam overlay is only kept with keep_beams"; return SSD_E_INVALID; }
+            SSD_HIP(env, hipMemcpy(buf.data(), env->p.beam, buf.size(), hipMemcpyDeviceToHost));
+            for (int e = 0; e < E; ++e) std::memcpy(beam + (size_t)e * hw, buf.data() + (size_t)e * S, hw);
+        }
+    }
+    if (pos || orient) {
+        std::vector<uint32_t> ag((size_t)E * N);
+        if (!ag.empty()) SSD_HIP(env, hipMemcpy(ag.data(), env->p.agents, ag.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ag.size(); ++i) {
+            const uint32_t cell = ag[i] & 0xFFFFu;
+            if (pos) { pos[2 * i] = (int16_t)(cell / W); pos[2 * i + 1] = (int16_t)(cell % W); }
+            if (orient) orient[i] = (uint8_t)((ag[i] >> 16) & 3u);
+        }
+    }
+    if (episode || t) {
+        std::vector<uint4> hdr(E);
+        SSD_HIP(env, hipMemcpy(hdr.data(), env->p.hdr, hdr.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+        for (int e = 0; e < E; ++e) { if (episode) episode[e] = hdr[e].z; if (t) t[e] = hdr[e].y; }
+    }
+    return SSD_OK;
+}
+
+static uint32_t host_mix32(uint32_t x) {
+    x ^= x >> 17; x *= 0xED5AD4BBu; x ^= x >> 11; x *= 0xAC4C1B51u; x ^= x >> 15; x *= 0x31848BABu; x ^= x >> 14;
+    return x;
+}
+
+int ssd_set_state(ssd_env *env, const int8_t *world, const int8_t *beam, const int16_t *pos, const uint8_t *orient,
+                  const uint32_t *episode, const uint32_t *t) {
+    if (!env) return SSD_E_INVALID;
+    SSD_HIP(env, hipSetDevice(env->device));
+    SSD_HIP(env, hipDeviceSynchronize());
+    const int E = env->E, N = env->N, S = env->S, hw = env->H * env->W, W = env->W, H = env->H;
+    if (world || beam) {
+        std::vector<uint8_t> buf((size_t)E * S, 0);
+        if (world) {
+            for (int e = 0; e < E; ++e) std::memcpy(buf.data() + (size_t)e * S, world + (size_t)e * hw, hw);
+            SSD_HIP(env, hipMemcpy(env->p.world, buf.data(), buf.size(), hipMemcpyHostToDevice));
+        }
+        if (beam) {
+            if (!env->keep_beams) { env->err = "beam overlay is only kept with keep_beams"; return SSD_E_INVALID; }
+            for (int e = 0; e < E; ++e) std::memcpy(buf.data() + (size_t)e * S, beam + (size_t)e * hw, hw);
+            SSD_HIP(env, hipMemcpy(env->p.beam, buf.data(), buf.size(), hipMemcpyHostToDevice));
+        }
+    }
+    if ((pos || orient) && N > 0) {
+        std::vector<uint32_t> ag((size_t)E * N);
+        SSD_HIP(env, hipMemcpy(ag.data(), env->p.agents, ag.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ag.size(); ++i) {
+            uint32_t cell = ag[i] & 0xFFFFu, o = (ag[i] >> 16) & 3u;
+            if (pos) {
+                const int r = pos[2 * i], c = pos[2 * i + 1];
+                if (r < 0 || r >= H || c < 0 || c >= W) { env->err = "agent position outside the map"; return SSD_E_INVALID; }
+                cell = (uint32_t)(r * W + c);
+            }
+            if (orient) { if (orient[i] > 3) { env->err = "orientation code must be 0..3"; return SSD_E_INVALID; } o = orient[i]; }
+            ag[i] = cell | (o << 16);
+        }
+        SSD_HIP(env, hipMemcpy(env->p.agents, ag.data(), ag.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (episode || t) {
+        std::vector<uint4> hdr(E);
+        SSD_HIP(env, hipMemcpy(hdr.data(), env->p.hdr, hdr.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+        for (int e = 0; e < E; ++e) {
+            if (t) hdr[e].y = t[e];
+            if (episode) {
+                hdr[e].z = episode[e];
+                uint32_t h = 0x243F6A88u;         // env_key(seed, env, episode), prng.py
+                h = host_mix32(h ^ (uint32_t)env->seed);
+                h = host_mix32(h ^ (uint32_t)(env->seed >> 32));
+                h = host_mix32(h ^ (env->env_base + (uint32_t)e));
+                h = host_mix32(h ^ episode[e]);
+                hdr[e].x = h;
+            }
+        }
+        SSD_HIP(env, hipMemcpy(env->p.hdr, hdr.data(), hdr.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    }
+    return SSD_OK;
+}
+
+int ssd_render_full(ssd_env *env, int32_t e, uint8_t *rgb) {
+    if (!env || !rgb || e < 0 || e >= env->E) return SSD_E_INVALID;
+    SSD_HIP(env, hipSetDevice(env->device));
+    const size_t bytes = (size_t)env->H * env->W * 3;
+    if (!env->st_rgb) { int rc = dev_alloc(env, &env->st_rgb, bytes); if (rc) return rc; }
+    SSD_HIP(env, hipDeviceSynchronize());
+    ssd::launch_render_full(env->p, e, env->st_rgb, nullptr);
+    SSD_HIP(env, hipGetLastError());
+    SSD_HIP(env, hipMemcpy(rgb, env->st_rgb, bytes, hipMemcpyDeviceToHost));
+    return SSD_OK;
+}
+
+int ssd_potential_waste_area(const ssd_env *env) { return env ? env->potential_waste : SSD_E_INVALID; }
+
+int ssd_device_status(ssd_env *env, uint32_t *status, int clear) {
+    if (!env || !status) return SSD_E_INVALID;
+    SSD_HIP(env, hipSetDevice(env->device));
+    SSD_HIP(env, hipDeviceSynchronize());
+    SSD_HIP(env, hipMemcpy(status, env->p.status, 4, hipMemcpyDeviceToHost));
+    if (clear) SSD_HIP(env, hipMemset(env->p.status, 0, 4));
+    return SSD_OK;
+}
+
+int ssd_synchronize(ssd_env *env) {
+    if (!env) return SSD_E_INVALID;
+    SSD_HIP(env, hipSetDevice(env->device));
+    SSD_HIP(env, hipDeviceSynchronize());
+    return SSD_OK;
+}
+
+}  // extern "C"

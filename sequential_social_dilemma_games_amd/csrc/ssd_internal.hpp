@@ -1,0 +1,61 @@
+// csrc/ssd_internal.hpp -- kernel parameter block shared by ssd_kernels.hip and ssd_capi.hip.
+#pragma once
+#include <stdint.h>
+
+namespace ssd {
+
+constexpr int kWave = 64;          // CDNA wavefront width
+constexpr int kEnvsPerBlock = 4;   // one wavefront per env, 4 envs per 256-thread workgroup
+constexpr int kMaxAgents = 64;     // lanes = agents in the move / beam phases
+constexpr int kMaxCells = 4096;    // H*W, bounded by the u64 per-lane spawn bitmask and by LDS
+constexpr int kMaxBeamLen = 21;    // 3 rays * beam_len lanes must fit one wavefront
+
+// cellinfo bits (static per map)
+constexpr uint8_t kInfoApple = 1;  // base 'A' (Harvest) / 'B' (Cleanup): apple spawn point
+constexpr uint8_t kInfoWaste = 2;  // base 'H' or 'R': potential waste cell
+
+enum Mode : int32_t { kModeStep = 0, kModeReset = 1, kModeObserve = 2 };
+
+// PRNG streams (sequential_social_dilemma_games_amd/prng.py)
+enum Stream : uint32_t {
+    kSpawnPoint = 1, kSpawnRot = 2, kMove = 3, kApple = 4, kWasteCoin = 5, kWasteOrder = 6, kAction = 7
+};
+
+struct Params {
+    // dimensions
+    int32_t E, N, H, W, S;         // S = H*W rounded up to 16 (per-env stride of the grids in HBM)
+    int32_t view_len, V, beam_len;
+    int32_t mode, rotate, keep_beams, num_actions_random;
+    uint32_t w_magic;              // floor(2^32 / W) + 1 : cell / W for cell < 2^16
+    uint32_t per_env_magic, vv_magic, v_magic;   // same for N*V*V, V*V, V (observation index decode)
+    uint32_t seed_lo, seed_hi, env_base;
+    int32_t n_spawn, n_thr;
+    // engine state in HBM
+    uint8_t *world;                // [E][S]  ASCII cells
+    uint8_t *beam;                 // [E][S]  beam overlay (keep_beams only), 0 = none
+    uint32_t *agents;              // [E][N]  cell | orient << 16
+    uint4 *hdr;                    // [E]     {key, t, episode, 0}
+    uint32_t *status;              // [1]     SSD_ST_* bits
+    // static tables in HBM (L2-resident)
+    const uint8_t *cellinfo;       // [S]
+    const uint8_t *reset_world;    // [S]     world right after reset_map()
+    const uint16_t *spawn_cells;   // [n_spawn]
+    const uint32_t *lut;           // [128]   r | g << 8 | b << 16
+    const uint64_t *thr_ca;        // [n_thr] Cleanup apple thresholds by #'H'
+    const uint64_t *thr_cw;        // [n_thr] Cleanup waste thresholds by #'H'
+    uint64_t thr_h[4];             // Harvest apple thresholds by min(#neighbour apples, 3)
+    // per-call I/O (device pointers; any may be null)
+    const int32_t *actions;        // [E][N]
+    const uint8_t *order;          // [E][N]
+    const uint8_t *mask;           // [E]     reset only
+    int32_t *actions_out;          // [E][N]
+    uint8_t *obs;                  // [E][N][V][V][3]
+    int32_t *rew;                  // [E][N]
+    uint8_t *done;                 // [E][N]
+};
+
+size_t lds_bytes(int S);
+void launch(const Params &p, int game, void *stream);
+void launch_render_full(const Params &p, int e, uint8_t *rgb_dev, void *stream);
+
+}  // namespace ssd

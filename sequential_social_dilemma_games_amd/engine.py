@@ -1,0 +1,211 @@
+"""Batched engine: E independent Harvest / Cleanup envs resident in the HBM of one MI355X.
+
+This is the throughput API behind the dict-API env classes (map_env.py): actions i32 [E,N] in,
+uint8 observations [E,N,V,V,3], i32 rewards and u8 dones out, one fused HIP kernel launch per
+step (csrc/ssd_kernels.hip) reached through the C ABI of include/ssd.h.
+
+Two calling styles:
+  * device tensors (`reset`, `step`, `step_random`, `observe`): torch is used only to own the
+    output buffers and to name the HIP stream; calls are asynchronous on torch's current stream;
+  * host arrays (`*_host`): numpy in / numpy out, the library stages through its own device
+    buffers and returns when the results have landed.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from . import config as cfgmod
+from . import constants as K
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class VecEngine(object):
+    def __init__(self, game, ascii_map=None, num_envs=1, num_agents=1, view_len=K.VIEW_LEN, beam_len=K.BEAM_LEN,
+                 seed=0, env_index_base=0, device=0, keep_beams=False, color_map=None):
+        self.game = int(game)
+        if ascii_map is None:
+            ascii_map = K.HARVEST_MAP if self.game == K.GAME_HARVEST else K.CLEANUP_MAP
+        self.ascii_map = [str(r) for r in ascii_map]
+        flat, self.H, self.W = cfgmod.ascii_to_bytes(self.ascii_map)
+        self.E, self.N = int(num_envs), int(num_agents)
+        self.view_len, self.V, self.beam_len = int(view_len), 2 * int(view_len) + 1, int(beam_len)
+        self.seed, self.env_index_base, self.device = int(seed), int(env_index_base), int(device)
+        self.keep_beams = bool(keep_beams)
+        self.num_actions = 8 if self.game == K.GAME_HARVEST else 9     # harvest.py:44, cleanup.py:70
+        self._lut = np.ascontiguousarray(cfgmod.make_lut(color_map))
+        self._thr_h = cfgmod.harvest_thresholds()
+        self.potential_waste_area = cfgmod.potential_waste_area(self.ascii_map) if self.game == K.GAME_CLEANUP else 0
+        self._thr_ca, self._thr_cw = cfgmod.cleanup_thresholds(self.potential_waste_area)
+        self._flat = flat
+        c = _capi.SsdConfig()
+        c.struct_size = C.sizeof(_capi.SsdConfig)
+        c.game, c.height, c.width, c.base_map = self.game, self.H, self.W, flat
+        c.num_envs, c.num_agents, c.view_len, c.beam_len = self.E, self.N, self.view_len, self.beam_len
+        c.seed, c.env_index_base, c.device_id, c.keep_beams = self.seed, self.env_index_base, self.device, int(self.keep_beams)
+        c.color_lut = self._lut.ctypes.data
+        c.harvest_thresholds = self._thr_h.ctypes.data
+        c.cleanup_apple_thresholds = self._thr_ca.ctypes.data
+        c.cleanup_waste_thresholds = self._thr_cw.ctypes.data
+        self._h = C.c_void_p()
+        L = _capi.lib()
+        _capi.check(L.ssd_create(C.byref(c), C.byref(self._h)))
+        self._L = L
+        if L.ssd_potential_waste_area(self._h) != self.potential_waste_area:
+            raise _capi.SsdError("potential_waste_area mismatch between host and library")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.ssd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ device-tensor API
+    def _torch(self):
+        import torch
+        return torch, torch.device("cuda", self.device)
+
+    def _stream(self):
+        torch, dev = self._torch()
+        return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def alloc_outputs(self):
+        """(obs u8 [E,N,V,V,3], rew i32 [E,N], done u8 [E,N]) on the engine's device."""
+        torch, dev = self._torch()
+        return (torch.empty((self.E, self.N, self.V, self.V, 3), dtype=torch.uint8, device=dev),
+                torch.empty((self.E, self.N), dtype=torch.int32, device=dev),
+                torch.empty((self.E, self.N), dtype=torch.uint8, device=dev))
+
+    @staticmethod
+    def _dp(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def _check_tensor(self, t, shape, dtype, name):
+        torch, dev = self._torch()
+        if t.device != dev or t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+            raise ValueError("%s must be a contiguous %s tensor of shape %s on %s" % (name, dtype, tuple(shape), dev))
+
+    def reset(self, mask=None, obs=None):
+        """MapEnv.reset (map_env.py:214-249) for every env (or those with mask != 0).  Returns obs."""
+        torch, dev = self._torch()
+        if obs is None:
+            obs = (torch.zeros if mask is not None else torch.empty)(
+                (self.E, self.N, self.V, self.V, 3), dtype=torch.uint8, device=dev)
+        self._check_tensor(obs, (self.E, self.N, self.V, self.V, 3), torch.uint8, "obs")
+        if mask is not None:
+            self._check_tensor(mask, (self.E,), torch.uint8, "mask")
+        _capi.check(self._L.ssd_reset(self._h, self._dp(mask), self._dp(obs), 0, self._stream()), self._h)
+        return obs
+
+    def step(self, actions, order=None, out=None):
+        """MapEnv.step (map_env.py:152-212) on every env.  actions: i32 [E,N] (-1 = absent);
+        order: optional u8 [E,N] action-dict order.  Returns (obs, rew, done) device tensors."""
+        torch, dev = self._torch()
+        self._check_tensor(actions, (self.E, self.N), torch.int32, "actions")
+        if order is not None:
+            self._check_tensor(order, (self.E, self.N), torch.uint8, "order")
+        obs, rew, done = out if out is not None else self.alloc_outputs()
+        _capi.check(self._L.ssd_step(self._h, self._dp(actions), self._dp(order), self._dp(obs), self._dp(rew),
+                                     self._dp(done), 0, self._stream()), self._h)
+        return obs, rew, done
+
+    def step_random(self, out=None, actions_out=None, num_actions=None):
+        """One step with uniform random actions drawn on the device (rollout.py:62-70)."""
+        obs, rew, done = out if out is not None else self.alloc_outputs()
+        na = self.num_actions if num_actions is None else int(num_actions)
+        _capi.check(self._L.ssd_step_random(self._h, na, self._dp(actions_out), self._dp(obs), self._dp(rew),
+                                            self._dp(done), 0, self._stream()), self._h)
+        return obs, rew, done
+
+    def observe(self, rotate=True, obs=None):
+        torch, dev = self._torch()
+        if obs is None:
+            obs = torch.empty((self.E, self.N, self.V, self.V, 3), dtype=torch.uint8, device=dev)
+        _capi.check(self._L.ssd_observe(self._h, self._dp(obs), 0 if rotate else _capi.SSD_NO_ROTATE,
+                                        self._stream()), self._h)
+        return obs
+
+    # ------------------------------------------------------------------ host-array API
+    def _host_out(self):
+        return (np.zeros((self.E, self.N, self.V, self.V, 3), np.uint8), np.zeros((self.E, self.N), np.int32),
+                np.zeros((self.E, self.N), np.uint8))
+
+    def reset_host(self, mask=None):
+        obs = np.zeros((self.E, self.N, self.V, self.V, 3), np.uint8)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.E)
+        _capi.check(self._L.ssd_reset(self._h, _ptr(m), _ptr(obs), _capi.SSD_HOST_PTRS, None), self._h)
+        return obs
+
+    def step_host(self, actions, order=None):
+        actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.E, self.N)
+        if order is not None:
+            order = np.ascontiguousarray(order, dtype=np.uint8).reshape(self.E, self.N)
+        obs, rew, done = self._host_out()
+        _capi.check(self._L.ssd_step(self._h, _ptr(actions), _ptr(order), _ptr(obs), _ptr(rew), _ptr(done),
+                                     _capi.SSD_HOST_PTRS, None), self._h)
+        return obs, rew, done
+
+    def step_random_host(self):
+        act = np.zeros((self.E, self.N), np.int32)
+        obs, rew, done = self._host_out()
+        _capi.check(self._L.ssd_step_random(self._h, self.num_actions, _ptr(act), _ptr(obs), _ptr(rew), _ptr(done),
+                                            _capi.SSD_HOST_PTRS, None), self._h)
+        return act, obs, rew, done
+
+    def observe_host(self, rotate=True):
+        obs = np.zeros((self.E, self.N, self.V, self.V, 3), np.uint8)
+        flags = _capi.SSD_HOST_PTRS | (0 if rotate else _capi.SSD_NO_ROTATE)
+        _capi.check(self._L.ssd_observe(self._h, _ptr(obs), flags, None), self._h)
+        return obs
+
+    # ------------------------------------------------------------------ state access
+    def get_state(self):
+        E, N, H, W = self.E, self.N, self.H, self.W
+        s = dict(world=np.zeros((E, H, W), np.int8), beam=np.zeros((E, H, W), np.int8) if self.keep_beams else None,
+                 pos=np.zeros((E, N, 2), np.int16), orient=np.zeros((E, N), np.uint8),
+                 episode=np.zeros(E, np.uint32), t=np.zeros(E, np.uint32))
+        _capi.check(self._L.ssd_get_state(self._h, _ptr(s["world"]), _ptr(s["beam"]), _ptr(s["pos"]), _ptr(s["orient"]),
+                                          _ptr(s["episode"]), _ptr(s["t"])), self._h)
+        return s
+
+    def set_state(self, world=None, beam=None, pos=None, orient=None, episode=None, t=None):
+        E, N, H, W = self.E, self.N, self.H, self.W
+
+        def prep(a, dt, shape, name):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=dt)
+            if a.shape != shape:
+                raise ValueError("%s must have shape %s, got %s" % (name, shape, a.shape))
+            return a
+        world, beam = prep(world, np.int8, (E, H, W), "world"), prep(beam, np.int8, (E, H, W), "beam")
+        pos, orient = prep(pos, np.int16, (E, N, 2), "pos"), prep(orient, np.uint8, (E, N), "orient")
+        episode, t = prep(episode, np.uint32, (E,), "episode"), prep(t, np.uint32, (E,), "t")
+        _capi.check(self._L.ssd_set_state(self._h, _ptr(world), _ptr(beam), _ptr(pos), _ptr(orient), _ptr(episode),
+                                          _ptr(t)), self._h)
+
+    def render_full(self, e=0):
+        """map_to_colors() of the whole grid of env e (map_env.py:316-339): u8 [H,W,3]."""
+        rgb = np.zeros((self.H, self.W, 3), np.uint8)
+        _capi.check(self._L.ssd_render_full(self._h, int(e), _ptr(rgb)), self._h)
+        return rgb
+
+    def status(self, clear=True):
+        st = C.c_uint32(0)
+        _capi.check(self._L.ssd_device_status(self._h, C.byref(st), int(clear)), self._h)
+        return st.value
+
+    def synchronize(self):
+        _capi.check(self._L.ssd_synchronize(self._h), self._h)
+
+    # ------------------------------------------------------------------ bookkeeping for bench / roofline
+    def algorithmic_bytes_per_env_step(self):
+        return cfgmod.algorithmic_bytes_per_env_step(self.H, self.W, self.N, self.V)

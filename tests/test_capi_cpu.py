@@ -1,0 +1,52 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol include/ssd.h
+declares, agrees with the ctypes struct layout, and refuses to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from sequential_social_dilemma_games_amd import _capi
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "ssd.h")).read()
+    declared = set(re.findall(r"\b(ssd_[a-z_]+)\s*\(", header))
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+    L = _capi.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.ssd_abi_version() == _capi.ABI_VERSION
+
+
+def test_create_rejects_bad_configs_and_needs_a_gpu():
+    import torch
+    L = _capi.lib()
+    c = _capi.SsdConfig()
+    h = C.c_void_p()
+    c.struct_size = 4
+    assert L.ssd_create(C.byref(c), C.byref(h)) == _capi.SSD_E_INVALID
+    c.struct_size = C.sizeof(_capi.SsdConfig)
+    c.game, c.height, c.width, c.num_envs, c.num_agents, c.view_len, c.beam_len = 0, 3, 4, 1, 1, 7, 5
+    c.base_map = b"@@@@" b"@ P " b"@@@@"                       # open border
+    assert L.ssd_create(C.byref(c), C.byref(h)) == _capi.SSD_E_INVALID
+    assert b"border" in L.ssd_last_error(None)
+    c.base_map = b"@@@@" b"@ P@" b"@@@@"
+    rc = L.ssd_create(C.byref(c), C.byref(h))
+    if torch.cuda.is_available():
+        assert rc == 0
+        L.ssd_destroy(h)
+    else:
+        assert rc == _capi.SSD_E_DEVICE                          # no CPU path, by design
+        assert b"no CPU path" in L.ssd_last_error(None)
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from sequential_social_dilemma_games_amd.engine import VecEngine
+    with pytest.raises(_capi.SsdError):
+        VecEngine(0, None, num_envs=1, num_agents=1)

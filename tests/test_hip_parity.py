@@ -1,0 +1,170 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (libssd_hip.so), against
+(a) the golden transitions recorded from the reference and (b) the C oracle on the same seeded
+inputs.  Integer / byte work: the bar is bit-exact."""
+import numpy as np
+import pytest
+
+import golden_util as G
+from oracle import pyoracle
+from sequential_social_dilemma_games_amd import constants as K
+from sequential_social_dilemma_games_amd.engine import VecEngine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", G.group_names())
+def test_hip_replays_reference_transitions(name):
+    g = G.load(name)
+    eng = VecEngine(g.game, g.map, num_envs=1, num_agents=g.N, view_len=g.view_len, seed=g.seed,
+                    env_index_base=g.env, keep_beams=True)
+    s = g.steps
+    zero_beam = np.zeros((1, eng.H, eng.W), np.int8)
+    for k in range(g.n_steps):
+        eng.set_state(world=s["pre_world"][k][None], beam=zero_beam, pos=s["pre_pos"][k][None],
+                      orient=s["pre_orient"][k][None], episode=np.array([s["episode"][k]], np.uint32),
+                      t=np.array([s["t"][k] - 1], np.uint32))
+        obs, rew, done = eng.step_host(s["act"][k][None], order=s["order"][k][None])
+        st = eng.get_state()
+        where = "%s step %d" % (name, k)
+        np.testing.assert_array_equal(st["pos"][0], s["pos"][k], err_msg=where)
+        np.testing.assert_array_equal(st["orient"][0], s["orient"][k], err_msg=where)
+        np.testing.assert_array_equal(st["world"][0], s["world"][k], err_msg=where)
+        np.testing.assert_array_equal(st["beam"][0], s["beam"][k], err_msg=where)
+        np.testing.assert_array_equal(rew[0], s["rew"][k], err_msg=where)
+        np.testing.assert_array_equal(obs[0], s["obs"][k], err_msg=where)
+        assert st["t"][0] == s["t"][k] and not done.any()
+    r = g.resets
+    for k in range(g.n_resets):
+        ep = int(r["episode"][k])
+        eng.set_state(episode=np.array([(ep - 1) & 0xFFFFFFFF], np.uint32))
+        obs = eng.reset_host()
+        st = eng.get_state()
+        where = "%s reset %d" % (name, k)
+        assert st["episode"][0] == ep and st["t"][0] == 0
+        np.testing.assert_array_equal(st["pos"][0], r["pos"][k], err_msg=where)
+        np.testing.assert_array_equal(st["orient"][0], r["orient"][k], err_msg=where)
+        np.testing.assert_array_equal(st["world"][0], r["world"][k], err_msg=where)
+        np.testing.assert_array_equal(obs[0], r["obs"][k], err_msg=where)
+    assert eng.status() == 0
+
+
+CASES = [
+    # game, map, E, N, view_len, steps
+    (K.GAME_HARVEST, K.HARVEST_MAP, 257, 5, 7, 60),          # E % 4 != 0 exercises the ragged last workgroup
+    (K.GAME_CLEANUP, K.CLEANUP_MAP, 128, 5, 7, 60),
+    (K.GAME_CLEANUP, K.CLEANUP_MAP, 66, 10, 7, 40),
+    (K.GAME_HARVEST, K.harvest_map_25x38(), 64, 5, 7, 40),
+    (K.GAME_CLEANUP, K.cleanup_map_48x36(), 33, 10, 7, 40),
+    (K.GAME_HARVEST, ['@@@@@@@', '@PAPAP@', '@APAPA@', '@PAPAP@', '@@@@@@@'], 512, 6, 2, 80),
+    (K.GAME_CLEANUP, ['@@@@@@@', '@PHBPP@', '@RPBPH@', '@PHBPP@', '@@@@@@@'], 512, 5, 3, 80),
+    (K.GAME_HARVEST, ['@@@@@@@', '@PPPPP@', '@PPPPP@', '@PPPPP@', '@@@@@@@'], 300, 13, 1, 60),
+    (K.GAME_HARVEST, K.HARVEST_MAP, 3, 0, 7, 5),             # no agents
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_hip_rollout_matches_oracle(case):
+    """Free-running random-action rollouts (device-drawn actions) on E envs: every state array
+    and output must equal the oracle's at every step, including a masked mid-rollout reset."""
+    game, amap, E, N, v, steps = CASES[case]
+    seed, base = 1234 + case, 1000 * case
+    eng = VecEngine(game, amap, num_envs=E, num_agents=N, view_len=v, seed=seed, env_index_base=base, keep_beams=True)
+    ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), view_len=v, seed=seed, env_base=base)
+    np.testing.assert_array_equal(eng.reset_host(), ora.reset())
+
+    def same_state(where):
+        a, b = eng.get_state(), ora.get_state()
+        for k in ("world", "beam", "pos", "orient", "episode", "t"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg="%s: %s" % (where, k))
+
+    same_state("after reset")
+    for s in range(steps):
+        act, obs, rew, done = eng.step_random_host()
+        o_act, o_obs, o_rew, o_done = ora.step_random()
+        np.testing.assert_array_equal(act, o_act, err_msg="actions step %d" % s)
+        np.testing.assert_array_equal(rew, o_rew, err_msg="rew step %d" % s)
+        np.testing.assert_array_equal(obs, o_obs, err_msg="obs step %d" % s)
+        np.testing.assert_array_equal(done, o_done)
+        same_state("step %d" % s)
+        if s == steps // 2:
+            mask = (np.arange(E) % 3 == 1).astype(np.uint8)
+            h_obs, o_obs = eng.reset_host(mask), ora.reset(mask)
+            sel = mask.astype(bool)
+            np.testing.assert_array_equal(h_obs[sel], o_obs[sel])
+            assert not h_obs[~sel].any()                     # rows of envs that were not reset stay untouched
+            same_state("after masked reset")
+    np.testing.assert_array_equal(eng.observe_host(rotate=True), ora.observe(True))
+    np.testing.assert_array_equal(eng.observe_host(rotate=False), ora.observe(False))
+    assert eng.status() == 0
+
+
+def test_hip_explicit_actions_orders_and_subsets():
+    """Arbitrary action-dict orders and subsets (tests/test_envs.py:437-438,594-597 style) on a
+    crowded map, given as actions + order arrays."""
+    amap = ['@@@@@@@', '@PPPPP@', '@PPPPP@', '@PPPPP@', '@@@@@@@']
+    E, N = 256, 7
+    rng = np.random.RandomState(7)
+    eng = VecEngine(K.GAME_HARVEST, amap, num_envs=E, num_agents=N, view_len=2, seed=99, keep_beams=True)
+    ora = pyoracle.Oracle(K.GAME_HARVEST, amap, E, N, G.default_lut(), view_len=2, seed=99)
+    eng.reset_host(); ora.reset()
+    for s in range(60):
+        act = rng.randint(0, 8, size=(E, N)).astype(np.int32)
+        order = np.full((E, N), 0xFF, np.uint8)
+        for e in range(E):
+            k = rng.randint(0, N + 1)
+            perm = rng.permutation(N)[:k]
+            order[e, :k] = perm
+            absent = np.setdiff1d(np.arange(N), perm)
+            act[e, absent] = -1
+        obs, rew, done = eng.step_host(act, order)
+        o_obs, o_rew, _ = ora.step(act, order)
+        np.testing.assert_array_equal(rew, o_rew, err_msg="step %d" % s)
+        np.testing.assert_array_equal(obs, o_obs, err_msg="step %d" % s)
+        a, b = eng.get_state(), ora.get_state()
+        for k in ("world", "beam", "pos", "orient"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg="step %d %s" % (s, k))
+    assert eng.status() == 0
+
+
+def test_device_tensor_api_matches_host_api():
+    import torch
+    E, N = 64, 5
+    a = VecEngine(K.GAME_HARVEST, None, num_envs=E, num_agents=N, seed=5)
+    b = VecEngine(K.GAME_HARVEST, None, num_envs=E, num_agents=N, seed=5)
+    obs_a = a.reset()
+    obs_b = b.reset_host()
+    assert np.array_equal(obs_a.cpu().numpy(), obs_b)
+    rng = np.random.RandomState(0)
+    for s in range(20):
+        act = rng.randint(0, 8, size=(E, N)).astype(np.int32)
+        o, r, d = a.step(torch.from_numpy(act).cuda())
+        ho, hr, hd = b.step_host(act)
+        assert np.array_equal(o.cpu().numpy(), ho) and np.array_equal(r.cpu().numpy(), hr)
+        assert np.array_equal(d.cpu().numpy(), hd)
+    assert a.status() == 0 and b.status() == 0
+
+
+def test_bad_action_sets_status_and_is_ignored():
+    eng = VecEngine(K.GAME_HARVEST, None, num_envs=2, num_agents=2, seed=1)
+    eng.reset_host()
+    before = eng.get_state()
+    eng.step_host(np.array([[8, 4], [4, 99]], np.int32))     # CLEAN does not exist in Harvest (KeyError in the reference)
+    assert eng.status() & 1
+    after = eng.get_state()
+    np.testing.assert_array_equal(before["pos"], after["pos"])
+
+
+def test_render_full_matches_lut_of_overlay():
+    eng = VecEngine(K.GAME_CLEANUP, None, num_envs=3, num_agents=5, seed=3, keep_beams=True)
+    ora = pyoracle.Oracle(K.GAME_CLEANUP, K.CLEANUP_MAP, 3, 5, G.default_lut(), seed=3)
+    eng.reset_host(); ora.reset()
+    for _ in range(10):
+        eng.step_random_host(); ora.step_random()
+    st = ora.get_state()
+    lut = G.default_lut()
+    for e in range(3):
+        grid = st["world"][e].copy()
+        for i in range(5):
+            grid[st["pos"][e, i, 0], st["pos"][e, i, 1]] = ord("12345"[i])
+        grid = np.where(st["beam"][e] != 0, st["beam"][e], grid)
+        np.testing.assert_array_equal(eng.render_full(e), lut[grid.astype(np.int64)])
