@@ -36,6 +36,27 @@ class SsdError(RuntimeError):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7).  Two HIP
+    runtimes in one process cannot both initialise the GPU, so bind libssd_hip.so to the copy torch
+    will use: load it first, and the dynamic linker resolves our NEEDED entry to it by SONAME.
+    Without torch installed the system runtime (/opt/rocm) is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        return C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    return None
+
+
+_hip_runtime = None
+
+
 def lib():
     """The loaded library; raises SsdError when the HIP extension has not been built."""
     global _lib
@@ -44,7 +65,9 @@ def lib():
             raise SsdError("HIP extension missing: %s (build it with `python -c 'import __graft_entry__ as g; "
                            "g.build()'` or `make -C sequential_social_dilemma_games_amd/csrc`); there is no CPU "
                            "fallback" % LIB_PATH)
+        global _hip_runtime
         try:
+            _hip_runtime = _preload_torch_hip_runtime()
             L = C.CDLL(LIB_PATH)
         except OSError as exc:
             raise SsdError("cannot load %s: %s (no CPU fallback)" % (LIB_PATH, exc))
