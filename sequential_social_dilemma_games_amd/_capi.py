@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libssd_hip.so")
+# SSD_LIB_PATH lets tools/phase_profile.py load the diagnostic (stamped) build of the SAME sources.
+LIB_PATH = os.environ.get("SSD_LIB_PATH") or os.path.join(_PKG, "libssd_hip.so")
 
 SSD_OK, SSD_E_INVALID, SSD_E_DEVICE, SSD_E_NOMEM, SSD_E_STATE = 0, -1, -2, -3, -4
 SSD_HOST_PTRS, SSD_NO_ROTATE = 1, 2

@@ -164,7 +164,7 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
     if (!cfg->base_map || H < 3 || W < 3 || H > 4095 || W > 4095 || (long)H * W > ssd::kMaxCells)
         return fail_create("map must be 3..4095 on a side with at most 4096 cells", SSD_E_INVALID);
     if (E < 1 || N < 0 || N > ssd::kMaxAgents) return fail_create("need num_envs >= 1 and 0 <= num_agents <= 64", SSD_E_INVALID);
-    if (cfg->view_len < 0 || (long)N * V * V > 16383) return fail_create("num_agents * (2*view_len+1)^2 must be <= 16383", SSD_E_INVALID);
+    if (cfg->view_len < 0 || cfg->view_len > 15) return fail_create("view_len must be 0..15", SSD_E_INVALID);
     if (cfg->beam_len < 0 || cfg->beam_len > ssd::kMaxBeamLen) return fail_create("beam_len must be 0..21", SSD_E_INVALID);
     const int hw = H * W;
     // Appendix C.11 of SURVEY.md: the reference indexes out of range on maps without a closed wall
@@ -190,13 +190,13 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
     env->S = S;
 
     // static per-map tables (map_env.py:93-101, harvest.py:22-26, cleanup.py:44-62)
-    std::vector<uint8_t> cellinfo(S, 0), reset_world(S, 0);
-    std::vector<uint16_t> spawn_cells;
+    std::vector<uint8_t> reset_world(S, 0);
+    std::vector<uint16_t> spawn_cells, apple_cells, waste_cells;
     const char apple_ch = cfg->game == SSD_GAME_HARVEST ? 'A' : 'B';
     for (int c = 0; c < hw; ++c) {
         const char b = cfg->base_map[c];
-        if (b == apple_ch) cellinfo[c] |= ssd::kInfoApple;
-        if (cfg->game == SSD_GAME_CLEANUP && (b == 'H' || b == 'R')) { cellinfo[c] |= ssd::kInfoWaste; env->potential_waste++; }
+        if (b == apple_ch) apple_cells.push_back((uint16_t)c);
+        if (cfg->game == SSD_GAME_CLEANUP && (b == 'H' || b == 'R')) { waste_cells.push_back((uint16_t)c); env->potential_waste++; }
         if (b == 'P') spawn_cells.push_back((uint16_t)c);
         char w = ' ';                         // reset_map (:560-564) + custom_reset (harvest.py:57-60, cleanup.py:84-92)
         if (b == '@') w = '@';
@@ -233,9 +233,10 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
     p.view_len = cfg->view_len; p.V = V; p.beam_len = cfg->beam_len;
     p.keep_beams = env->keep_beams;
     p.w_magic = magic((uint32_t)W);
-    p.per_env_magic = magic((uint32_t)(N * V * V)); p.vv_magic = magic((uint32_t)(V * V)); p.v_magic = magic((uint32_t)V);
+    p.v_magic16 = (65536u + (uint32_t)V - 1u) / (uint32_t)V;
     p.seed_lo = (uint32_t)cfg->seed; p.seed_hi = (uint32_t)(cfg->seed >> 32); p.env_base = cfg->env_index_base;
     p.n_spawn = (int)spawn_cells.size(); p.n_thr = n_thr;
+    p.n_apple = (int)apple_cells.size(); p.n_waste = (int)waste_cells.size();
     const double sp[4] = {0, 0.005, 0.02, 0.05};   // harvest.py:13 SPAWN_PROB
     for (int i = 0; i < 4; ++i) p.thr_h[i] = cfg->harvest_thresholds ? cfg->harvest_thresholds[i] : threshold(sp[i]);
 
@@ -260,12 +261,14 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
         if (hipMemcpy(p.world, w0.data(), w0.size(), hipMemcpyHostToDevice) != hipSuccess) { env->err = "hipMemcpy(world)"; return bail(SSD_E_DEVICE); }
     }
     uint8_t *d8; uint16_t *d16; uint32_t *d32; uint64_t *d64;
-    if ((rc = upload(env, &d8, cellinfo))) return bail(rc);
-    p.cellinfo = d8;
     if ((rc = upload(env, &d8, reset_world))) return bail(rc);
     p.reset_world = d8;
     if ((rc = upload(env, &d16, spawn_cells))) return bail(rc);
     p.spawn_cells = d16;
+    if ((rc = upload(env, &d16, apple_cells))) return bail(rc);
+    p.apple_cells = d16;
+    if ((rc = upload(env, &d16, waste_cells))) return bail(rc);
+    p.waste_cells = d16;
     if ((rc = upload(env, &d32, lut))) return bail(rc);
     p.lut = d32;
     if ((rc = upload(env, &d64, thr_ca))) return bail(rc);
@@ -357,6 +360,11 @@ int ssd_set_state(ssd_env *env, const int8_t *world, const int8_t *beam, const i
     const int E = env->E, N = env->N, S = env->S, hw = env->H * env->W, W = env->W, H = env->H;
     if (world || beam) {
         std::vector<uint8_t> buf((size_t)E * S, 0);
+        // glyphs index the 128-entry colour table on the device: cells must be 7-bit ASCII
+        for (size_t i = 0; world && i < (size_t)E * hw; ++i)
+            if (world[i] <= 0) { env->err = "world cells must be 7-bit ASCII (1..127)"; return SSD_E_INVALID; }
+        for (size_t i = 0; beam && i < (size_t)E * hw; ++i)
+            if (beam[i] < 0) { env->err = "beam cells must be 0 or 7-bit ASCII"; return SSD_E_INVALID; }
         if (world) {
             for (int e = 0; e < E; ++e) std::memcpy(buf.data() + (size_t)e * S, world + (size_t)e * hw, hw);
             SSD_HIP(env, hipMemcpy(env->p.world, buf.data(), buf.size(), hipMemcpyHostToDevice));
@@ -424,6 +432,15 @@ int ssd_device_status(ssd_env *env, uint32_t *status, int clear) {
     if (clear) SSD_HIP(env, hipMemset(env->p.status, 0, 4));
     return SSD_OK;
 }
+
+#ifdef SSD_STAMPS
+// Diagnostic library only (make stamps): device buffer [E][16] u64 that the kernel fills with cycle stamps.
+int ssd_debug_set_stamps(ssd_env *env, void *dev_ptr) {
+    if (!env) return SSD_E_INVALID;
+    env->p.stamps = static_cast<unsigned long long *>(dev_ptr);
+    return SSD_OK;
+}
+#endif
 
 int ssd_synchronize(ssd_env *env) {
     if (!env) return SSD_E_INVALID;

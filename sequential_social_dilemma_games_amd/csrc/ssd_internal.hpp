@@ -10,9 +10,7 @@ constexpr int kMaxAgents = 64;     // lanes = agents in the move / beam phases
 constexpr int kMaxCells = 4096;    // H*W, bounded by the u64 per-lane spawn bitmask and by LDS
 constexpr int kMaxBeamLen = 21;    // 3 rays * beam_len lanes must fit one wavefront
 
-// cellinfo bits (static per map)
-constexpr uint8_t kInfoApple = 1;  // base 'A' (Harvest) / 'B' (Cleanup): apple spawn point
-constexpr uint8_t kInfoWaste = 2;  // base 'H' or 'R': potential waste cell
+constexpr int kListRegs = 3;       // per-lane registers holding the first 192 entries of a static cell list
 
 enum Mode : int32_t { kModeStep = 0, kModeReset = 1, kModeObserve = 2 };
 
@@ -27,9 +25,9 @@ struct Params {
     int32_t view_len, V, beam_len;
     int32_t mode, rotate, keep_beams, num_actions_random;
     uint32_t w_magic;              // floor(2^32 / W) + 1 : cell / W for cell < 2^16
-    uint32_t per_env_magic, vv_magic, v_magic;   // same for N*V*V, V*V, V (observation index decode)
+    uint32_t v_magic16;            // ceil(2^16 / V): pp / V == (pp * v_magic16) >> 16 for pp < V*V, V <= 31
     uint32_t seed_lo, seed_hi, env_base;
-    int32_t n_spawn, n_thr;
+    int32_t n_spawn, n_thr, n_apple, n_waste;
     // engine state in HBM
     uint8_t *world;                // [E][S]  ASCII cells
     uint8_t *beam;                 // [E][S]  beam overlay (keep_beams only), 0 = none
@@ -37,9 +35,10 @@ struct Params {
     uint4 *hdr;                    // [E]     {key, t, episode, 0}
     uint32_t *status;              // [1]     SSD_ST_* bits
     // static tables in HBM (L2-resident)
-    const uint8_t *cellinfo;       // [S]
     const uint8_t *reset_world;    // [S]     world right after reset_map()
-    const uint16_t *spawn_cells;   // [n_spawn]
+    const uint16_t *spawn_cells;   // [n_spawn] 'P' cells, row-major (map_env.py:96-99)
+    const uint16_t *apple_cells;   // [n_apple] 'A' (harvest.py:22-26) / 'B' (cleanup.py:53-54) cells, row-major
+    const uint16_t *waste_cells;   // [n_waste] 'H' or 'R' cells (cleanup.py:59-60), row-major
     const uint32_t *lut;           // [128]   r | g << 8 | b << 16
     const uint64_t *thr_ca;        // [n_thr] Cleanup apple thresholds by #'H'
     const uint64_t *thr_cw;        // [n_thr] Cleanup waste thresholds by #'H'
@@ -52,6 +51,7 @@ struct Params {
     uint8_t *obs;                  // [E][N][V][V][3]
     int32_t *rew;                  // [E][N]
     uint8_t *done;                 // [E][N]
+    unsigned long long *stamps;    // [E][16] s_memtime stamps; diagnostic builds (-DSSD_STAMPS) only, else null
 };
 
 size_t lds_bytes(int S);

@@ -8,11 +8,15 @@
 //     ballots ("who stands on cell x" = ballot, last index = highest set bit), the order-dependent
 //     parts of the reference algorithm run as wave-uniform loops (map_env.py:357-543);
 //   * beams: lanes = (ray, step) pairs, stop positions from ballots (map_env.py:566-649);
-//   * respawn: lanes = cells, 3x3 stencil on the LDS grid, counter-based PRNG keyed on the cell
+//   * respawn: lanes = entries of the map's static apple / waste cell lists (held in registers),
+//     3x3 stencil on the LDS grid, counter-based PRNG keyed on the cell
 //     (harvest.py:75-104, cleanup.py:132-171);
-//   * observation: after a workgroup barrier all 256 lanes render the 4 envs' N x 15 x 15 x 3
-//     windows from the LDS overlay, 4 cells = 12 contiguous bytes per lane per store, so a
-//     wavefront store covers 768 contiguous bytes of the uint8 obs tensor (map_env.py:189-199).
+//   * observation: the wave renders its env's N agents from the LDS overlay, lane = 4 consecutive
+//     cells of the 15 x 15 window = 12 contiguous bytes per store, so a wavefront store covers up to
+//     768 contiguous bytes of the uint8 obs tensor (map_env.py:189-199);
+//   * waves never touch each other's LDS: the kernel has no workgroup barrier.
+// The kernel is latency-bound (4 waves per SIMD at 4096 envs), so cross-lane reductions use DPP /
+// scalar loops instead of LDS-crossbar shuffles, and LDS reads are issued in independent batches.
 // No MFMA: the path is integer / indexing work bounded by HBM traffic.
 //
 // Reference citations are file:line of the reference repository (social_dilemmas/envs/...).
@@ -26,6 +30,8 @@ namespace ssd {
 constexpr uint32_t kStBadAction = 1u << 0;
 constexpr uint32_t kStNoSpawn = 1u << 1;
 constexpr uint32_t kStMoveLookup = 1u << 2;
+
+constexpr int kObsBatch = 5;       // agents rendered per pass of the observation phase
 
 // ---------------------------------------------------------------------------------------------
 // shared PRNG (prng.py): triple32 chain
@@ -58,6 +64,7 @@ __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_re
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint64_t bit(uint32_t i) { return 1ull << i; }
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // Lanes of one wavefront communicate through LDS without a workgroup barrier (LDS operations of a
 // wave complete in order); this only has to stop the compiler from moving LDS accesses across it.
@@ -67,26 +74,31 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { uint32_t w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
-    return rfl(v);
-}
+// Full-wave reductions: inclusive scan inside each row of 16 lanes with DPP row_shr (VALU latency,
+// no LDS crossbar), then the four row totals (lanes 15/31/47/63) are combined on the scalar unit.
+#define SSD_DPP(old, v, ctrl, bc) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(v), ctrl, 0xF, 0xF, bc))
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return rfl(v);
+    v += SSD_DPP(0, v, 0x111, true);   // row_shr:1, out-of-row lanes read 0
+    v += SSD_DPP(0, v, 0x112, true);   // row_shr:2
+    v += SSD_DPP(0, v, 0x114, true);   // row_shr:4
+    v += SSD_DPP(0, v, 0x118, true);   // row_shr:8
+    return rl(v, 15) + rl(v, 31) + rl(v, 47) + rl(v, 63);
 }
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        uint32_t lo = __shfl_xor((uint32_t)v, o, 64), hi = __shfl_xor((uint32_t)(v >> 32), o, 64);
-        uint64_t w = ((uint64_t)hi << 32) | lo;
-        v = w < v ? w : v;
-    }
-    return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = umin(v, SSD_DPP(0xFFFFFFFFu, v, 0x111, false));   // out-of-row lanes keep `old` = identity
+    v = umin(v, SSD_DPP(0xFFFFFFFFu, v, 0x112, false));
+    v = umin(v, SSD_DPP(0xFFFFFFFFu, v, 0x114, false));
+    v = umin(v, SSD_DPP(0xFFFFFFFFu, v, 0x118, false));
+    return umin(umin(rl(v, 15), rl(v, 31)), umin(rl(v, 47), rl(v, 63)));
 }
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) { return ~wave_min_u64(~v); }
+// Smallest (hi, lo) pair over the lanes with `has`; exact also when hi == 0xFFFFFFFF.  Returns "any lane has".
+__device__ __forceinline__ bool wave_argmin_pair(bool has, uint32_t hi, uint32_t lo, uint32_t &out_hi, uint32_t &out_lo) {
+    if (!ballot(has)) return false;
+    const uint32_t mh = wave_min_u32(has ? hi : 0xFFFFFFFFu);
+    const uint32_t ml = wave_min_u32((has && hi == mh) ? lo : 0xFFFFFFFFu);
+    out_hi = mh; out_lo = ml;
+    return true;
+}
 
 // map_env.py:290 + the '<U1' array dtype (:85): str(int(agent_id[-1]) + 1) truncated to one char.
 __device__ __forceinline__ uint8_t agent_glyph(uint32_t i) {
@@ -113,43 +125,61 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
     uint32_t m = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
     return (m >> 7) * 0xFFu;
 }
+// number of bytes of x equal to ch
+__device__ __forceinline__ uint32_t count_bytes_eq(uint32_t x, uint32_t ch) {
+    const uint32_t y = x ^ (ch * 0x01010101u);
+    return (uint32_t)__builtin_popcount(~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u);
+}
+
+// Per-phase cycle stamps for tools/phase_profile.py: compiled only into the diagnostic library
+// (make stamps); the product build contains no stamp code.
+#ifdef SSD_STAMPS
+#define SSD_STAMP(i)                                                                               \
+    do {                                                                                           \
+        if (p.stamps && lane == 0 && e < p.E) p.stamps[(size_t)e * 16 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define SSD_STAMP(i)
+#endif
 
 // ---------------------------------------------------------------------------------------------
-// LDS layout of one workgroup
-//   lut[128] u32 | agent[4][64] u32 | flag[4] u32 | cellinfo[S] | per wave: world[S] beam[S] occ[S]
+// LDS layout of one workgroup: per wave (= per env)  lut[128] u32 | world[S] | beam[S] | occ[S]
+// Waves never read each other's LDS, so the kernel has no workgroup barrier.
 // ---------------------------------------------------------------------------------------------
-__host__ size_t lds_bytes(int S) { return 128 * 4 + kEnvsPerBlock * 64 * 4 + 16 + (size_t)S + (size_t)kEnvsPerBlock * 3 * S; }
+__host__ size_t lds_bytes(int S) { return (size_t)kEnvsPerBlock * (128 * 4 + 3 * (size_t)S); }
 
 template <int GAME>
 __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int S = p.S, N = p.N, W = p.W, H = p.H;
-    uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *s_agent = s_lut + 128;
-    uint32_t *s_flag = s_agent + kEnvsPerBlock * 64;
-    uint8_t *s_info = reinterpret_cast<uint8_t *>(s_flag + 4);
-    uint8_t *s_grids = s_info + S;
-    uint8_t *s_world = s_grids + (size_t)wv * 3 * S;
+    uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + (size_t)wv * (512 + 3 * (size_t)S));
+    uint8_t *s_world = reinterpret_cast<uint8_t *>(s_lut + 128);
     uint8_t *s_beam = s_world + S;
     uint8_t *s_occ = s_beam + S;
-
-    // static tables: colour LUT and per-cell spawn info, shared by the 4 envs of the workgroup
-    if (tid < 128) s_lut[tid] = p.lut[tid];
-    for (int i = tid * 16; i < S; i += 256 * 16)
-        *reinterpret_cast<uint4 *>(s_info + i) = *reinterpret_cast<const uint4 *>(p.cellinfo + i);
 
     const int e = blockIdx.x * kEnvsPerBlock + wv;
     const int mode = p.mode;
     bool active = e < p.E;                                   // wave-uniform
     if (active && mode == kModeReset && p.mask) active = p.mask[e] != 0;
-    if (lane == 0) s_flag[wv] = active ? 1u : 0u;
-    __syncthreads();                                         // s_info / s_lut visible to all waves
+    SSD_STAMP(0);
 
     if (active) {
         const bool is_agent = lane < N;
         const uint4 hdr = p.hdr[e];
+        // glyph -> RGB table of the observation phase, one copy per wave
+        const uint32_t lut_a = p.obs ? p.lut[lane] : 0u, lut_b = p.obs ? p.lut[lane + 64] : 0u;
+        // static cell lists of the map: the first 64*kListRegs entries live in registers and are
+        // fetched together with the env state, so their latency is paid once, in the prologue
+        uint32_t alist[kListRegs], wlist[kListRegs];
+#pragma unroll
+        for (int j = 0; j < kListRegs; ++j) {
+            const int idx = lane + 64 * j;
+            alist[j] = (mode != kModeObserve && idx < p.n_apple) ? p.apple_cells[idx] : 0u;
+            wlist[j] = (GAME == 1 && mode != kModeObserve && idx < p.n_waste) ? p.waste_cells[idx] : 0u;
+        }
         uint32_t key = rfl(hdr.x), t = rfl(hdr.y), episode = rfl(hdr.z);
+        s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b;
         uint32_t status = 0;
         uint32_t cell = 0, orient = 2;                       // per-lane agent state (lane = agent index)
         int rew = 0;
@@ -169,18 +199,18 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
             // spawn_rotation (:664-667) indexes [LEFT, RIGHT, UP, DOWN].
             const uint32_t pk_pt = phase_key(key, 0, kSpawnPoint), pk_rot = phase_key(key, 0, kSpawnRot);
             for (int i = 0; i < N; ++i) {
-                uint64_t best = 0;
+                bool has = false;
+                uint32_t bh = 0, bl = 0;                     // lane-local min of (~draw, ~cell) = max of (draw, cell)
                 for (int s = lane; s < p.n_spawn; s += 64) {
                     const uint32_t c = p.spawn_cells[s];
                     if (s_occ[c] == 0) {
-                        const uint64_t k = (((uint64_t)draw(pk_pt, ((uint32_t)i << 16) | c) << 32) | c) + 1;
-                        best = k > best ? k : best;
+                        const uint32_t kh = ~draw(pk_pt, ((uint32_t)i << 16) | c), kl = ~c;
+                        if (!has || kh < bh || (kh == bh && kl < bl)) { bh = kh; bl = kl; has = true; }
                     }
                 }
-                best = wave_max_u64(best);
-                uint32_t chosen = 0;
-                if (best == 0) { status |= kStNoSpawn; chosen = p.n_spawn ? p.spawn_cells[0] : (uint32_t)(W + 1); }
-                else chosen = (uint32_t)(best - 1) & 0xFFFFu;
+                uint32_t oh, ol, chosen;
+                if (wave_argmin_pair(has, bh, bl, oh, ol)) chosen = ~ol;
+                else { status |= kStNoSpawn; chosen = p.n_spawn ? p.spawn_cells[0] : (uint32_t)(W + 1); }
                 if (lane == i) { cell = chosen; orient = randint(draw(pk_rot, (uint32_t)i), 4); }
                 s_occ[chosen] = agent_glyph((uint32_t)i);    // all lanes, same address, same value
                 wave_sync();
@@ -189,20 +219,21 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
             // ---- load env state: grid -> LDS (16 B per lane), agents -> lanes ----
             const uint8_t *gw = p.world + (size_t)e * S;
             const bool load_beam = mode == kModeObserve && p.keep_beams;
-            for (int i = lane * 16; i < S; i += 64 * 16) {
-                *reinterpret_cast<uint4 *>(s_world + i) = *reinterpret_cast<const uint4 *>(gw + i);
-                uint4 bv = make_uint4(0, 0, 0, 0);
-                if (load_beam) bv = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + i);
-                *reinterpret_cast<uint4 *>(s_beam + i) = bv;
-                *reinterpret_cast<uint4 *>(s_occ + i) = make_uint4(0, 0, 0, 0);
-            }
             if (is_agent) {
                 const uint32_t a = p.agents[(size_t)e * N + lane];
                 cell = a & 0xFFFFu; orient = (a >> 16) & 3u;
             }
+            for (int i = lane * 16; i < S; i += 64 * 16) {
+                uint4 bv = make_uint4(0, 0, 0, 0);
+                if (load_beam) bv = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + i);
+                *reinterpret_cast<uint4 *>(s_world + i) = *reinterpret_cast<const uint4 *>(gw + i);
+                *reinterpret_cast<uint4 *>(s_beam + i) = bv;
+                *reinterpret_cast<uint4 *>(s_occ + i) = make_uint4(0, 0, 0, 0);
+            }
             wave_sync();
         }
 
+        SSD_STAMP(1);   // state loaded
         int act = -1;
         uint32_t ordv = (uint32_t)lane;                      // action order list, lane k = k-th acting agent
         int nord = N;
@@ -247,7 +278,20 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
             }
             uint32_t mvcell = tcell;                         // agent_moves[id] (:410)
             const uint64_t M = ballot(mover);
-            if (M) {                                         // :415
+            // Fast path.  If no mover's target is a cell some OTHER agent stands on and no two movers
+            // share a target, every branch of :424-543 degenerates to "each mover takes its target"
+            // whatever the shuffle says (STAY / wall-blocked movers target their own cell and stay), and
+            // since draws are counter-keyed there is no RNG state to advance.  Otherwise run the
+            // reference algorithm in full.
+            bool clash = false;
+            for (int j = 0; j < N; ++j) {
+                const uint32_t cj = rl(cell, j), tj = rl(tcell, j);
+                clash |= mover && j != lane && (tcell == cj || (((M >> j) & 1) && tcell == tj));
+            }
+            const bool slow = ballot(clash) != 0;
+            if (!slow) {
+                if (mover) cell = tcell;
+            } else {                                         // :415 (M != 0 here)
                 const int nm = __builtin_popcountll(M);
                 uint32_t perm = 0;                           // lane k: k-th entry of the (shuffled) zipped list
                 {
@@ -265,14 +309,20 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
                     if (lane == (int)j) perm = vi;
                 }
                 uint64_t Hm = M;                             // ids that still have an entry in agent_moves
-                // :424-491 cells wanted by several agents, in lexicographic order (np.unique, axis=0)
-                int cur = -1;
-                while (true) {
-                    const uint32_t nxt = wave_min_u32((mover && (int)tcell > cur) ? tcell : 0xFFFFFFFFu);
-                    if (nxt == 0xFFFFFFFFu) break;
-                    cur = (int)nxt;
-                    const uint64_t Cm = ballot(mover && tcell == nxt);
-                    if (__builtin_popcountll(Cm) < 2) continue;                     // :436
+                // :424-491 cells wanted by several agents, in lexicographic order (np.unique, axis=0).
+                // Contested targets are rare: find them with one pass of lane compares, then visit them
+                // in ascending cell order (scalar min over the few lanes involved).
+                bool dup = false;
+                for (uint64_t m = M; m; m &= m - 1) {
+                    const int j = __builtin_ctzll(m);
+                    dup |= mover && j != lane && rl(tcell, j) == tcell;
+                }
+                uint64_t todo = ballot(dup);
+                while (todo) {
+                    uint32_t nxt = 0xFFFFFFFFu;
+                    for (uint64_t m = todo; m; m &= m - 1) nxt = umin(nxt, rl(tcell, __builtin_ctzll(m)));
+                    const uint64_t Cm = ballot(mover && tcell == nxt);              // contenders (:441-442)
+                    todo &= ~Cm;
                     bool cell_free = true;
                     const uint64_t Pm = ballot(is_agent && cell == nxt);            // :449 move in self.agent_pos
                     if (Pm) {
@@ -324,30 +374,35 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
             }
         }
 
+        SSD_STAMP(2);   // moves resolved
         if (mode != kModeReset) {
-            // ---- consume (map_env.py:178-181, agent.py:177-183) in index order + occupancy layer ----
-            // Every lane runs the same LDS ops on the same address, so the loop is sequential per lane
-            // and needs no cross-lane ordering.  s_occ holds the glyph of the LAST agent on a cell.
-            for (int i = 0; i < N; ++i) {
-                const uint32_t ci = rl(cell, i);
-                if (mode == kModeStep && s_world[ci] == 'A') {
-                    s_world[ci] = ' ';
-                    if (lane == i) rew += 1;
-                }
-                s_occ[ci] = agent_glyph((uint32_t)i);
+            // ---- consume (map_env.py:178-181, agent.py:177-183) + occupancy layer ----
+            // Index order means: of several agents on one cell the LOWEST index eats the apple, and
+            // agent_by_pos / the overlay show the HIGHEST index (:289-297, :603).
+            bool lower = false, higher = false;
+            for (int j = 0; j < N; ++j) {
+                const bool same = is_agent && rl(cell, j) == cell;
+                lower |= same && j < lane;
+                higher |= same && j > lane;
             }
+            if (mode == kModeStep && is_agent && !lower && s_world[cell] == 'A') { s_world[cell] = ' '; rew += 1; }
+            if (is_agent && !higher) s_occ[cell] = agent_glyph((uint32_t)lane);
             wave_sync();
         }
 
+        SSD_STAMP(3);   // consume + occupancy
         if (mode == kModeStep) {
             // ---- update_custom_moves (map_env.py:545-552): beams in action order ----
             const int L = p.beam_len;
             const uint32_t rmask = (1u << L) - 1u;
-            for (int k = 0; k < nord; ++k) {
+            constexpr int kFire = 7, kClean = 8;
+            uint64_t shooters = ballot(is_agent && (act == kFire || (GAME == 1 && act == kClean)));
+            for (int k = 0; shooters && k < nord; ++k) {
                 const uint32_t a = rl(ordv, k);
+                if (!((shooters >> a) & 1)) continue;
+                shooters &= ~bit(a);
                 const int aa = (int)rl((uint32_t)act, a);
-                const bool fire = aa == 7, clean = GAME == 1 && aa == 8;            // harvest.py:62-67, cleanup.py:94-111
-                if (!fire && !clean) continue;
+                const bool fire = aa == kFire, clean = !fire;                       // harvest.py:62-67, cleanup.py:94-111
                 if (fire && lane == (int)a) rew -= 1;                               // agent.py:170-172 fire_beam('F')
                 // update_map_fire (map_env.py:566-649): lane = (ray q, step kk)
                 const uint32_t pc = rl(cell, a);
@@ -393,59 +448,97 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
             }
         }
 
+        SSD_STAMP(4);   // beams
         if (mode != kModeObserve) {
             // ---- custom_map_update (map_env.py:187 / :230): respawn ----
-            uint64_t spawn_bits = 0;                                                // bit j: cell lane + 64*j gets an apple
+            // Lanes walk the map's static apple-point list (row-major, as the reference iterates it).
+            // The LDS reads of one list entry are unconditional (padding entries point at an interior
+            // cell), so they go out as one independent batch.
+            uint64_t spawn_bits = 0;                                                // bit j: list entry lane + 64*j gets an apple
             const uint32_t pk_apple = phase_key(key, t, kApple);
+            const int a_iters = (p.n_apple + 63) >> 6;
+            const uint32_t safe = (uint32_t)(W + 1);                                // cell (1,1)
+            uint32_t waste_cell = 0xFFFFFFFFu;
             if (GAME == 0) {
                 // harvest.py:75-104 spawn_apples.  Apple points are interior cells (the border is wall),
                 // so the 3x3 neighbourhood (j*j + k*k <= 2 on the radius-2 box, :90-92) is always in bounds.
-                int j = 0;
-                for (int c = lane; c < S; c += 64, ++j) {
-                    if ((s_info[c] & kInfoApple) && s_world[c] != 'A' && s_occ[c] == 0) {      // :88
-                        int n = 0;
+                auto body = [&](int j, uint32_t c, bool valid) {
+                    c = valid ? c : safe;
+                    const uint8_t w = s_world[c], o = s_occ[c];
+                    int n = 0;
 #pragma unroll
-                        for (int dr = -1; dr <= 1; ++dr)
+                    for (int dr = -1; dr <= 1; ++dr)
 #pragma unroll
-                            for (int dc = -1; dc <= 1; ++dc) n += s_world[c + dr * W + dc] == 'A';
-                        const uint64_t thr = n == 0 ? p.thr_h[0] : n == 1 ? p.thr_h[1] : n == 2 ? p.thr_h[2] : p.thr_h[3];
-                        if ((uint64_t)draw(pk_apple, (uint32_t)c) < thr) spawn_bits |= bit(j);  // :100-103
-                    }
+                        for (int dc = -1; dc <= 1; ++dc)
+                            if (dr != 0 || dc != 0) n += s_world[(int)c + dr * W + dc] == 'A';
+                    const uint64_t thr = n == 0 ? p.thr_h[0] : n == 1 ? p.thr_h[1] : n == 2 ? p.thr_h[2] : p.thr_h[3];   // :100
+                    const bool hit = valid && w != 'A' && o == 0 && (uint64_t)draw(pk_apple, c) < thr;   // :88, :101-103
+                    spawn_bits |= hit ? bit(j) : 0ull;
+                };
+                // the first kListRegs list entries of every lane are processed without branches (a lane past the
+                // end of the list is merely invalid), so their LDS reads are in flight together
+#pragma unroll
+                for (int j = 0; j < kListRegs; ++j) body(j, alist[j], lane + 64 * j < p.n_apple);
+                for (int j = kListRegs; j < a_iters; ++j) {
+                    const int idx = lane + 64 * j;
+                    body(j, idx < p.n_apple ? p.apple_cells[idx] : 0u, idx < p.n_apple);
                 }
-                wave_sync();                                                        // counts use the pre-spawn map (:73)
-                j = 0;
-                for (int c = lane; c < S; c += 64, ++j)
-                    if ((spawn_bits >> j) & 1) s_world[c] = 'A';
             } else {
                 // cleanup.py:113-116: compute_probabilities (:156-171) from the current waste count, then
                 // spawn_apples_and_waste (:132-154).  Thresholds come from a host-computed table.
                 uint32_t nh = 0;
-                for (int c = lane; c < S; c += 64) nh += s_world[c] == 'H';
-                nh = wave_sum_u32(nh);
+                for (int i = lane * 16; i < S; i += 64 * 16) {
+                    const uint4 qd = *reinterpret_cast<const uint4 *>(s_world + i);
+                    nh += count_bytes_eq(qd.x, 'H') + count_bytes_eq(qd.y, 'H') + count_bytes_eq(qd.z, 'H') + count_bytes_eq(qd.w, 'H');
+                }
+                nh = wave_sum_u32(nh);                                              // compute_permitted_area (:173-179)
                 nh = nh < (uint32_t)p.n_thr ? nh : (uint32_t)p.n_thr - 1;
                 const uint64_t thr_a = p.thr_ca[nh], thr_w = p.thr_cw[nh];
-                uint64_t best = ~0ull;
-                const uint32_t pk_coin = phase_key(key, t, kWasteCoin), pk_ord = phase_key(key, t, kWasteOrder);
-                int j = 0;
-                for (int c = lane; c < S; c += 64, ++j) {
-                    const uint8_t inf = s_info[c], w = s_world[c];
-                    if ((inf & kInfoApple) && w != 'A' && s_occ[c] == 0 &&
-                        (uint64_t)draw(pk_apple, (uint32_t)c) < thr_a) spawn_bits |= bit(j);   // :135-141
-                    // :144-153 shuffled scan, first non-'H' point whose coin succeeds (at most one per step)
-                    if (thr_w && (inf & kInfoWaste) && w != 'H' && (uint64_t)draw(pk_coin, (uint32_t)c) < thr_w) {
-                        const uint64_t kx = ((uint64_t)draw(pk_ord, (uint32_t)c) << 32) | (uint32_t)c;
-                        best = kx < best ? kx : best;
-                    }
+                auto apple = [&](int j, uint32_t c, bool valid) {                   // :135-141
+                    c = valid ? c : safe;
+                    const uint8_t w = s_world[c], o = s_occ[c];
+                    const bool hit = valid && w != 'A' && o == 0 && (uint64_t)draw(pk_apple, c) < thr_a;
+                    spawn_bits |= hit ? bit(j) : 0ull;
+                };
+#pragma unroll
+                for (int j = 0; j < kListRegs; ++j) apple(j, alist[j], lane + 64 * j < p.n_apple);
+                for (int j = kListRegs; j < a_iters; ++j) {
+                    const int idx = lane + 64 * j;
+                    apple(j, idx < p.n_apple ? p.apple_cells[idx] : 0u, idx < p.n_apple);
                 }
-                if (thr_w) best = wave_min_u64(best);
-                wave_sync();
-                j = 0;
-                for (int c = lane; c < S; c += 64, ++j)
-                    if ((spawn_bits >> j) & 1) s_world[c] = 'A';
-                if (best != ~0ull) s_world[(uint32_t)best] = 'H';                   // may land under an agent
+                if (thr_w) {
+                    // :144-153 shuffled scan, first non-'H' point whose coin succeeds (at most one per step):
+                    // order = ascending (ORDER draw, cell), coin keyed by cell.
+                    const uint32_t pk_coin = phase_key(key, t, kWasteCoin), pk_ord = phase_key(key, t, kWasteOrder);
+                    bool has = false;
+                    uint32_t bh = 0, bl = 0;
+                    auto waste = [&](uint32_t c, bool valid) {
+                        c = valid ? c : safe;
+                        const bool cand = valid && s_world[c] != 'H' && (uint64_t)draw(pk_coin, c) < thr_w;
+                        const uint32_t kh = draw(pk_ord, c);
+                        if (cand && (!has || kh < bh || (kh == bh && c < bl))) { bh = kh; bl = c; has = true; }
+                    };
+                    const int w_iters = (p.n_waste + 63) >> 6;
+#pragma unroll
+                    for (int j = 0; j < kListRegs; ++j) waste(wlist[j], lane + 64 * j < p.n_waste);
+                    for (int j = kListRegs; j < w_iters; ++j) {
+                        const int idx = lane + 64 * j;
+                        waste(idx < p.n_waste ? p.waste_cells[idx] : 0u, idx < p.n_waste);
+                    }
+                    uint32_t oh, ol;
+                    if (wave_argmin_pair(has, bh, bl, oh, ol)) waste_cell = ol;
+                }
             }
+            wave_sync();                                                            // counts use the pre-spawn map (harvest.py:73)
+#pragma unroll
+            for (int j = 0; j < kListRegs; ++j)
+                if ((spawn_bits >> j) & 1) s_world[alist[j]] = 'A';
+            for (int j = kListRegs; j < a_iters; ++j)
+                if ((spawn_bits >> j) & 1) s_world[p.apple_cells[lane + 64 * j]] = 'A';
+            if (waste_cell != 0xFFFFFFFFu) s_world[waste_cell] = 'H';               // may land under an agent
             wave_sync();
 
+            SSD_STAMP(5);   // respawn
             // ---- write the env back: grid, agents, header, rewards, dones ----
             uint8_t *gw = p.world + (size_t)e * S;
             for (int i = lane * 16; i < S; i += 64 * 16) {
@@ -465,6 +558,7 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
             wave_sync();
         }
 
+        SSD_STAMP(6);   // write-back issued
         // ---- get_map_with_agents (map_env.py:280-302): world <- agents <- beams, in place, 4 cells per op ----
         for (int i = lane * 4; i < S; i += 64 * 4) {
             const uint32_t w = *reinterpret_cast<const uint32_t *>(s_world + i);
@@ -475,74 +569,112 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
             v = (v & ~mb) | (b & mb);
             *reinterpret_cast<uint32_t *>(s_world + i) = v;
         }
-        if (is_agent) {
-            const uint32_t r = __umulhi(cell, p.w_magic), c = cell - r * (uint32_t)W;
-            s_agent[wv * 64 + lane] = r | (c << 12) | (orient << 24);
-        }
-    }
-    __syncthreads();
+        wave_sync();
+        SSD_STAMP(7);   // overlay built
+        SSD_STAMP(8);
 
-    // ---- per-agent observations (agent.py:76-78 -> utility_funcs.py:59-114 window with '0' padding,
-    //      map_env.py:316-339 colour LUT, :669-689 rotate_view), all 256 lanes over the 4 envs ----
-    if (!p.obs) return;
-    {
-        const int V = p.V, v = p.view_len, VV = V * V, per_env = N * VV;
-        const int env0 = blockIdx.x * kEnvsPerBlock;
-        const int nenv = min(kEnvsPerBlock, p.E - env0);
-        const int total = nenv * per_env;
-        uint8_t *out = p.obs + (size_t)env0 * per_env * 3;
-        const bool rotate = p.rotate != 0;
-        for (int g = tid; g * 4 < total; g += 256) {
-            const int f0 = g * 4;
-            int el = (int)__umulhi((uint32_t)f0, p.per_env_magic);
-            int rem = f0 - el * per_env;
-            int ag = (int)__umulhi((uint32_t)rem, p.vv_magic);
-            rem -= ag * VV;
-            int i = (int)__umulhi((uint32_t)rem, p.v_magic);
-            int j = rem - i * V;
-            uint32_t px[4];
-            uint32_t valid = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                px[q] = 0;
-                if (f0 + q < total && s_flag[el]) {
-                    valid |= 1u << q;
-                    const uint32_t info = s_agent[el * 64 + ag];
-                    const int r0 = info & 0xFFF, c0 = (info >> 12) & 0xFFF, o = (info >> 24) & 3;
-                    // np.rot90 count k: UP 0, LEFT 1, DOWN 2, RIGHT 3; out[i,j] = view[a,b]
-                    int a = i, b = j;
-                    if (rotate) {
-                        if (o == 0) { a = j; b = V - 1 - i; }
-                        else if (o == 3) { a = V - 1 - i; b = V - 1 - j; }
-                        else if (o == 1) { a = V - 1 - j; b = i; }
-                    }
-                    const int rr = r0 - v + a, cc = c0 - v + b;
-                    const uint8_t *grid = s_grids + (size_t)el * 3 * S;
-                    const uint32_t ch = (rr >= 0 && rr < H && cc >= 0 && cc < W) ? grid[rr * W + cc] : (uint32_t)'0';
-                    px[q] = s_lut[ch & 127u];
-                }
-                if (++j == V) { j = 0; if (++i == V) { i = 0; if (++ag == N) { ag = 0; ++el; } } }
+        // ---- per-agent observations (agent.py:76-78 -> utility_funcs.py:59-114 window with '0' padding,
+        //      map_env.py:316-339 colour LUT, :669-689 rotate_view).  The wave renders its own env's agents
+        //      one after the other: lane = 4 consecutive cells of the V x V window (12 contiguous output
+        //      bytes), so the window coordinates are per-lane constants, the agent's position and rotation
+        //      are scalars, and one wave store covers up to 768 contiguous bytes of the uint8 obs tensor.
+        //      An agent's block starts at a multiple of V*V*3 = 675 bytes, i.e. at any byte alignment:
+        //      the 12-byte stores rely on gfx9's unaligned global access. ----
+        if (p.obs) {
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            const int V = p.V, v = p.view_len, VV = V * V;
+            uint8_t *out_env = p.obs + (size_t)e * N * VV * 3;
+            // Per-agent constants, computed once with lane = agent and read back as scalars in the loop.
+            // Window cell (a, b) of an agent at (r0, c0) is grid cell (r0 - v + a, c0 - v + b); it is inside
+            // the map iff lo_a <= a <= lo_a + span_a and the same for b (packed 16-bit pairs below).
+            // The view is rot90^k of the window (rotate_view, map_env.py:669-689; UP 0, LEFT 1, DOWN 2,
+            // RIGHT 3; reset observations are not rotated):  k=0 (a,b) = (i,j);  k=1 (j, V-1-i);
+            // k=2 (V-1-i, V-1-j) = (V-1,V-1) - [k=0];  k=3 (V-1-j, i) = (V-1,V-1) - [k=1].
+            uint32_t a_lo = 0, a_span = 0, a_s0 = 0, a_k = 0;
+            if (is_agent) {
+                const int r0 = (int)__umulhi(cell, p.w_magic), c0 = (int)cell - r0 * W;
+                const int rb = r0 - v, cb = c0 - v;
+                const int lo_a = max(0, -rb), hi_a = min(V - 1, H - 1 - rb);
+                const int lo_b = max(0, -cb), hi_b = min(V - 1, W - 1 - cb);
+                a_lo = (uint32_t)lo_a | ((uint32_t)lo_b << 16);
+                a_span = (uint32_t)(hi_a - lo_a) | ((uint32_t)(hi_b - lo_b) << 16);
+                a_k = p.rotate ? (orient == 2 ? 0u : orient == 0 ? 1u : orient == 3 ? 2u : 3u) : 0u;
+                // grid index of window cell (a,b) = rb*W + cb + a*W + b; for k >= 2 it is s0 - lin(k & 1)
+                a_s0 = (uint32_t)(rb * W + cb + (a_k >= 2 ? (V - 1) * W + (V - 1) : 0));
             }
-            uint8_t *dst = out + (size_t)f0 * 3;
-            if (valid == 0xFu) {
-                typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-                struct __attribute__((packed, aligned(4))) P3 { u32x3 v; };
-                u32x3 d;
-                d.x = px[0] | (px[1] << 24);
-                d.y = (px[1] >> 8) | (px[2] << 16);
-                d.z = (px[2] >> 16) | (px[3] << 8);
-                reinterpret_cast<P3 *>(dst)->v = d;
-            } else {
+            const uint32_t pkv = (uint32_t)(V - 1) * 0x00010001u;
+            for (int base = 0; base < VV; base += 256) {
+                const int pp0 = base + 4 * lane;
+                uint32_t P0[4], P1[4];
+                int L0[4], L1[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if ((valid >> q) & 1) {
-                        dst[q * 3 + 0] = (uint8_t)px[q];
-                        dst[q * 3 + 1] = (uint8_t)(px[q] >> 8);
-                        dst[q * 3 + 2] = (uint8_t)(px[q] >> 16);
+                for (int q = 0; q < 4; ++q) {
+                    const int pp = pp0 + q;
+                    const int i = (int)(((uint32_t)pp * p.v_magic16) >> 16), j = pp - i * V;   // pp / V, pp % V
+                    P0[q] = (uint32_t)i | ((uint32_t)j << 16);
+                    P1[q] = (uint32_t)j | ((uint32_t)(V - 1 - i) << 16);
+                    L0[q] = i * W + j;
+                    L1[q] = j * W + (V - 1 - i);
+                }
+                const int ncell = VV - pp0;                                         // >= 4: full group
+                // kObsBatch agents per pass: all their grid reads go out together, then all LUT reads,
+                // then the stores (agents past N re-render agent N-1 and skip the store).
+                for (int ag0 = 0; ag0 < N; ag0 += kObsBatch) {
+                    uint32_t glyph[kObsBatch][4];
+#pragma unroll
+                    for (int u = 0; u < kObsBatch; ++u) {
+                        const int ag = min(ag0 + u, N - 1);
+                        const uint32_t lo = rl(a_lo, ag), span = rl(a_span, ag), k = rl(a_k, ag);
+                        const int s0 = (int)rl(a_s0, ag);
+                        const bool odd = (k & 1) != 0, neg = k >= 2;
+                        const int s1 = neg ? -1 : 1;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const uint32_t x = odd ? P1[q] : P0[q];
+                            const u16x2 xv = __builtin_bit_cast(u16x2, x), kv = __builtin_bit_cast(u16x2, pkv);
+                            const u16x2 ab = neg ? (u16x2)(kv - xv) : xv;           // (a, b)
+                            const u16x2 t = ab - __builtin_bit_cast(u16x2, lo);
+                            const u16x2 m = __builtin_elementwise_min(t, __builtin_bit_cast(u16x2, span));
+                            const bool inb = __builtin_bit_cast(uint32_t, m) == __builtin_bit_cast(uint32_t, t);
+                            const int lin = __mul24(odd ? L1[q] : L0[q], s1) + s0;
+                            // an out-of-map lin may point anywhere (LDS reads are range-checked by the hardware and
+                            // the value is discarded): '0' padding, utility_funcs.py:94-114
+                            const uint32_t ch = s_world[lin];
+                            glyph[u][q] = inb ? ch : (uint32_t)'0';
+                        }
                     }
+                    uint32_t px[kObsBatch][4];
+#pragma unroll
+                    for (int u = 0; u < kObsBatch; ++u)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) px[u][q] = s_lut[glyph[u][q]];
+#pragma unroll
+                    for (int u = 0; u < kObsBatch; ++u) {
+                        if (ag0 + u >= N) break;
+                        uint8_t *dst = out_env + ((size_t)(ag0 + u) * VV + pp0) * 3;
+                        if (ncell >= 4) {
+                            typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                            struct __attribute__((packed, aligned(1))) P3 { u32x3 v; };
+                            u32x3 d;
+                            d.x = px[u][0] | (px[u][1] << 24);
+                            d.y = (px[u][1] >> 8) | (px[u][2] << 16);
+                            d.z = (px[u][2] >> 16) | (px[u][3] << 8);
+                            reinterpret_cast<P3 *>(dst)->v = d;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 3; ++q)
+                                if (q < ncell) {
+                                    dst[q * 3 + 0] = (uint8_t)px[u][q];
+                                    dst[q * 3 + 1] = (uint8_t)(px[u][q] >> 8);
+                                    dst[q * 3 + 2] = (uint8_t)(px[u][q] >> 16);
+                                }
+                        }
+                    }
+                }
             }
         }
     }
+    SSD_STAMP(9);       // observations issued
 }
 
 // MapEnv.map_to_colors() on the whole grid of one env (map_env.py:316-339), one thread per cell.
