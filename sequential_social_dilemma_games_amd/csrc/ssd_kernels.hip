@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t count_bytes_eq(uint32_t x, uint32_t ch) {
 // ---------------------------------------------------------------------------------------------
 __host__ size_t lds_bytes(int S) { return (size_t)kEnvsPerBlock * (128 * 4 + 3 * (size_t)S); }
 
-template <int GAME>
+template <int GAME, int MODE>
 __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -158,19 +158,39 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
     uint8_t *s_beam = s_world + S;
     uint8_t *s_occ = s_beam + S;
 
+    // Kernel arguments are fetched lazily by default, one scalar-cache round trip per basic block that
+    // needs one.  Pin what the prologue needs into SGPRs here so that the loads go out as one batch.
+    asm volatile("" ::"s"(p.hdr), "s"(p.agents), "s"(p.world), "s"(p.lut), "s"(p.apple_cells), "s"(p.obs),
+                 "s"(p.actions), "s"(p.order), "s"(p.n_apple), "s"(p.num_actions_random), "s"(p.w_magic));
     const int e = blockIdx.x * kEnvsPerBlock + wv;
-    const int mode = p.mode;
+    constexpr int mode = MODE;                               // compile-time: step / reset / observe
     bool active = e < p.E;                                   // wave-uniform
     if (active && mode == kModeReset && p.mask) active = p.mask[e] != 0;
     SSD_STAMP(0);
 
     if (active) {
         const bool is_agent = lane < N;
+        // ---- prologue: every global load of the env is issued before the first use, so the HBM / L2
+        //      latency is paid once.  hdr, agents, the first 1 KiB of the grid (the whole grid of the
+        //      shipped maps), the static cell lists and the colour table.
         const uint4 hdr = p.hdr[e];
+        uint32_t areg = 0;
+        int act_in = -1;
+        uint32_t ord_in = 0xFFu;
+        if (mode != kModeReset && is_agent) areg = p.agents[(size_t)e * N + lane];
+        if (mode == kModeStep && is_agent) {
+            if (p.num_actions_random <= 0) act_in = p.actions[(size_t)e * N + lane];
+            if (p.order) ord_in = p.order[(size_t)e * N + lane];
+        }
+        const uint8_t *gsrc = mode == kModeReset ? p.reset_world : p.world + (size_t)e * S;
+        uint4 w0 = make_uint4(0, 0, 0, 0), b0 = make_uint4(0, 0, 0, 0);
+        if (lane * 16 < S) {
+            w0 = *reinterpret_cast<const uint4 *>(gsrc + lane * 16);
+            if (mode == kModeObserve && p.keep_beams) b0 = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + lane * 16);
+        }
         // glyph -> RGB table of the observation phase, one copy per wave
         const uint32_t lut_a = p.obs ? p.lut[lane] : 0u, lut_b = p.obs ? p.lut[lane + 64] : 0u;
-        // static cell lists of the map: the first 64*kListRegs entries live in registers and are
-        // fetched together with the env state, so their latency is paid once, in the prologue
+        // static cell lists of the map: the first 64*kListRegs entries live in registers
         uint32_t alist[kListRegs], wlist[kListRegs];
 #pragma unroll
         for (int j = 0; j < kListRegs; ++j) {
@@ -181,19 +201,28 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
         uint32_t key = rfl(hdr.x), t = rfl(hdr.y), episode = rfl(hdr.z);
         s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b;
         uint32_t status = 0;
-        uint32_t cell = 0, orient = 2;                       // per-lane agent state (lane = agent index)
+        uint32_t cell = areg & 0xFFFFu, orient = mode == kModeReset ? 2u : (areg >> 16) & 3u;   // lane = agent index
         int rew = 0;
+        // grid -> LDS (16 B per lane); beam and occupancy layers start empty
+        if (lane * 16 < S) {
+            *reinterpret_cast<uint4 *>(s_world + lane * 16) = w0;
+            *reinterpret_cast<uint4 *>(s_beam + lane * 16) = b0;
+            *reinterpret_cast<uint4 *>(s_occ + lane * 16) = make_uint4(0, 0, 0, 0);
+        }
+        for (int i = lane * 16 + 1024; i < S; i += 1024) {   // maps above 1024 cells
+            uint4 bv = make_uint4(0, 0, 0, 0);
+            if (mode == kModeObserve && p.keep_beams) bv = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + i);
+            *reinterpret_cast<uint4 *>(s_world + i) = *reinterpret_cast<const uint4 *>(gsrc + i);
+            *reinterpret_cast<uint4 *>(s_beam + i) = bv;
+            *reinterpret_cast<uint4 *>(s_occ + i) = make_uint4(0, 0, 0, 0);
+        }
+        wave_sync();
 
         if (mode == kModeReset) {
             // ---- MapEnv.reset (map_env.py:214-249) ----
             episode += 1; t = 0;
             key = env_key(p.seed_lo, p.seed_hi, p.env_base + (uint32_t)e, episode);
-            for (int i = lane * 16; i < S; i += 64 * 16) {   // reset_map (:560-564) + custom_reset
-                *reinterpret_cast<uint4 *>(s_world + i) = *reinterpret_cast<const uint4 *>(p.reset_world + i);
-                *reinterpret_cast<uint4 *>(s_beam + i) = make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4 *>(s_occ + i) = make_uint4(0, 0, 0, 0);
-            }
-            wave_sync();
+            // the grid loaded above is reset_map (:560-564) + custom_reset of the base map
             // setup_agents (harvest.py:46-55 / cleanup.py:118-130): spawn_point (map_env.py:651-662) takes
             // the LAST free point of a fresh shuffle = the free point with the largest (draw, cell);
             // spawn_rotation (:664-667) indexes [LEFT, RIGHT, UP, DOWN].
@@ -215,22 +244,6 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
                 s_occ[chosen] = agent_glyph((uint32_t)i);    // all lanes, same address, same value
                 wave_sync();
             }
-        } else {
-            // ---- load env state: grid -> LDS (16 B per lane), agents -> lanes ----
-            const uint8_t *gw = p.world + (size_t)e * S;
-            const bool load_beam = mode == kModeObserve && p.keep_beams;
-            if (is_agent) {
-                const uint32_t a = p.agents[(size_t)e * N + lane];
-                cell = a & 0xFFFFu; orient = (a >> 16) & 3u;
-            }
-            for (int i = lane * 16; i < S; i += 64 * 16) {
-                uint4 bv = make_uint4(0, 0, 0, 0);
-                if (load_beam) bv = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + i);
-                *reinterpret_cast<uint4 *>(s_world + i) = *reinterpret_cast<const uint4 *>(gw + i);
-                *reinterpret_cast<uint4 *>(s_beam + i) = bv;
-                *reinterpret_cast<uint4 *>(s_occ + i) = make_uint4(0, 0, 0, 0);
-            }
-            wave_sync();
         }
 
         SSD_STAMP(1);   // state loaded
@@ -246,14 +259,14 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
                     act = (int)randint(draw(pk, (uint32_t)lane), (uint32_t)p.num_actions_random);
                     if (p.actions_out) p.actions_out[(size_t)e * N + lane] = act;
                 }
-            } else if (is_agent) {
-                act = p.actions[(size_t)e * N + lane];
+            } else {
+                act = act_in;
             }
             constexpr int kNumActions = GAME == 0 ? 8 : 9;   // harvest.py:44, cleanup.py:70
             const bool bad = is_agent && (act < -1 || act >= kNumActions);
             if (ballot(bad)) { status |= kStBadAction; if (bad) act = -1; }
             if (p.order) {
-                ordv = is_agent ? (uint32_t)p.order[(size_t)e * N + lane] : 0xFFu;
+                ordv = ord_in;
                 if (ordv != 0xFFu && ordv >= (uint32_t)N) { ordv = 0xFFu; status |= kStBadAction; }
                 const uint64_t endm = ballot(ordv == 0xFFu);
                 nord = endm ? __builtin_ctzll(endm) : 64;
@@ -690,12 +703,21 @@ __global__ void ssd_render_full_kernel(const Params p, int e, uint8_t *rgb) {
     }
 }
 
+template <int GAME>
+static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+    switch (p.mode) {
+    case kModeStep: hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStep>), grid, block, lds, s, p); break;
+    case kModeReset: hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeReset>), grid, block, lds, s, p); break;
+    default: hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeObserve>), grid, block, lds, s, p); break;
+    }
+}
+
 void launch(const Params &p, int game, void *stream) {
     const dim3 grid((p.E + kEnvsPerBlock - 1) / kEnvsPerBlock), block(256);
     const size_t lds = lds_bytes(p.S);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (game == 0) hipLaunchKernelGGL(ssd_env_kernel<0>, grid, block, lds, s, p);
-    else hipLaunchKernelGGL(ssd_env_kernel<1>, grid, block, lds, s, p);
+    if (game == 0) launch_game<0>(p, grid, block, lds, s);
+    else launch_game<1>(p, grid, block, lds, s);
 }
 
 void launch_render_full(const Params &p, int e, uint8_t *rgb_dev, void *stream) {
