@@ -114,6 +114,11 @@ int ssd_get_state(ssd_env *env, int8_t *world, int8_t *beam, int16_t *pos, uint8
 int ssd_set_state(ssd_env *env, const int8_t *world, const int8_t *beam, const int16_t *pos,
                   const uint8_t *orient, const uint32_t *episode, const uint32_t *t);
 
+/* Cleanup only: waste_count u32 [E] = number of 'H' cells from which the last step / reset computed
+ * current_apple_spawn_prob and current_waste_spawn_prob (compute_probabilities, cleanup.py:115,156-171;
+ * it runs after the beams and before the spawn).  Host pointer, synchronous. */
+int ssd_get_waste_count(ssd_env *env, uint32_t *waste_count);
+
 /* MapEnv.map_to_colors() on the full grid of env e (map_env.py:316-339): rgb u8 [H,W,3], host pointer. */
 int ssd_render_full(ssd_env *env, int32_t e, uint8_t *rgb);
 

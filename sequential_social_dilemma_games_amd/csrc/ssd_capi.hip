@@ -347,6 +347,16 @@ int ssd_get_state(ssd_env *env, int8_t *world, int8_t *beam, int16_t *pos, uint8
     return SSD_OK;
 }
 
+int ssd_get_waste_count(ssd_env *env, uint32_t *waste_count) {
+    if (!env || !waste_count) return SSD_E_INVALID;
+    SSD_HIP(env, hipSetDevice(env->device));
+    SSD_HIP(env, hipDeviceSynchronize());
+    std::vector<uint4> hdr(env->E);
+    SSD_HIP(env, hipMemcpy(hdr.data(), env->p.hdr, hdr.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    for (int e = 0; e < env->E; ++e) waste_count[e] = hdr[e].w;
+    return SSD_OK;
+}
+
 static uint32_t host_mix32(uint32_t x) {
     x ^= x >> 17; x *= 0xED5AD4BBu; x ^= x >> 11; x *= 0xAC4C1B51u; x ^= x >> 15; x *= 0x31848BABu; x ^= x >> 14;
     return x;

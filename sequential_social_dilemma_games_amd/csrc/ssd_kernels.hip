@@ -472,6 +472,7 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
             const int a_iters = (p.n_apple + 63) >> 6;
             const uint32_t safe = (uint32_t)(W + 1);                                // cell (1,1)
             uint32_t waste_cell = 0xFFFFFFFFu;
+            uint32_t waste_count = 0;                                               // #'H' the probabilities were computed from
             if (GAME == 0) {
                 // harvest.py:75-104 spawn_apples.  Apple points are interior cells (the border is wall),
                 // so the 3x3 neighbourhood (j*j + k*k <= 2 on the radius-2 box, :90-92) is always in bounds.
@@ -505,6 +506,7 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
                     nh += count_bytes_eq(qd.x, 'H') + count_bytes_eq(qd.y, 'H') + count_bytes_eq(qd.z, 'H') + count_bytes_eq(qd.w, 'H');
                 }
                 nh = wave_sum_u32(nh);                                              // compute_permitted_area (:173-179)
+                waste_count = nh;
                 nh = nh < (uint32_t)p.n_thr ? nh : (uint32_t)p.n_thr - 1;
                 const uint64_t thr_a = p.thr_ca[nh], thr_w = p.thr_cw[nh];
                 auto apple = [&](int j, uint32_t c, bool valid) {                   // :135-141
@@ -566,7 +568,7 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
                     if (p.done) p.done[(size_t)e * N + lane] = 0;                   // get_done -> False (:209)
                 }
             }
-            if (lane == 0) p.hdr[e] = make_uint4(key, t, episode, 0);
+            if (lane == 0) p.hdr[e] = make_uint4(key, t, episode, waste_count);
             if (status && lane == 0) atomicOr(p.status, status);
             wave_sync();
         }

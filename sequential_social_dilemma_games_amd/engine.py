@@ -192,6 +192,12 @@ class VecEngine(object):
         _capi.check(self._L.ssd_set_state(self._h, _ptr(world), _ptr(beam), _ptr(pos), _ptr(orient), _ptr(episode),
                                           _ptr(t)), self._h)
 
+    def waste_count(self):
+        """u32 [E]: the number of 'H' cells the last step / reset computed the Cleanup spawn probabilities from."""
+        out = np.zeros(self.E, np.uint32)
+        _capi.check(self._L.ssd_get_waste_count(self._h, _ptr(out)), self._h)
+        return out
+
     def render_full(self, e=0):
         """map_to_colors() of the whole grid of env e (map_env.py:316-339): u8 [H,W,3]."""
         rgb = np.zeros((self.H, self.W, 3), np.uint8)
