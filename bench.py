@@ -68,20 +68,13 @@ def main():
     from sequential_social_dilemma_games_amd import constants as K
     from sequential_social_dilemma_games_amd.engine import VecEngine
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    from sequential_social_dilemma_games_amd import parallel
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    dist, rank, world, local_rank = parallel.init_process_group("nccl")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
     game, amap, n_agents = {
         "harvest": (K.GAME_HARVEST, K.HARVEST_MAP, 5),
@@ -91,21 +84,20 @@ def main():
     }[args.game]
     if args.agents is not None:
         n_agents = args.agents
-    E = args.envs
-    eng = VecEngine(game, amap, num_envs=E, num_agents=n_agents, seed=0, env_index_base=rank * E, device=local_rank)
+    E = args.envs                                  # per GPU (weak scaling); global batch = world * E
+    eng, start, count = parallel.make_sharded_engine(game, amap, world * E, n_agents, rank, world,
+                                                     local_rank=local_rank, seed=0)
+    assert (start, count) == (rank * E, E)
     out = eng.alloc_outputs()
-    gathered = None
-    if args.gather and dist is not None:
-        gathered = (torch.empty((world,) + tuple(out[0].shape), dtype=torch.uint8, device=out[0].device),
-                    torch.empty((world,) + tuple(out[1].shape), dtype=torch.int32, device=out[1].device))
+    do_gather = bool(args.gather and dist is not None)
 
     def one_step(k):
         if k % HORIZON == 0:
             eng.reset(obs=out[0])
         eng.step_random(out=out)
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered[0], out[0])
-            dist.all_gather_into_tensor(gathered[1], out[1])
+        if do_gather:                              # one batched tensor on every rank: RCCL all-gather over xGMI
+            parallel.all_gather_batch(dist, out[0], world * E, world)
+            parallel.all_gather_batch(dist, out[1], world * E, world)
 
     for k in range(args.warmup):
         one_step(k)
@@ -145,12 +137,19 @@ def main():
             "config": {"workload": "%s %dx%d, %d agents, %d envs per GPU, uniform random actions, reset every %d steps"
                                    % (args.game, eng.H, eng.W, n_agents, E, HORIZON),
                        "envs_per_gpu": E, "agents": n_agents, "obs": "uint8 [E,N,15,15,3]", "launches_per_step": 1,
-                       "gather": bool(gathered is not None), "parallelism": "env-shard x%d" % world},
+                       "gather": do_gather, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "ssd_env_kernel<%d>" % game, "bytes_per_env_step": bytes_env,
+                         "kernel": "ssd::ssd_env_kernel<%d, 0>" % game, "bytes_per_env_step": bytes_env,
                          "avg_launch_us": launch_us},
         }
+        # HBM bytes per launch from the PMC counters of the committed profile of this exact workload
+        # (tools/profile_gpu.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE correction)
+        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
+        tkey = {"harvest": "harvest_16x38_n5_e4096", "cleanup": "cleanup_25x18_n5_e4096"}.get(args.game)
+        if tkey and E == 4096 and args.agents is None and os.path.exists(tpath):
+            res["roofline"]["traffic"] = json.load(open(tpath))[tkey]["hbm_bytes_per_launch"]
+            res["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 PMC, same workload)"
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(game, amap, n_agents)
         print(json.dumps(res))

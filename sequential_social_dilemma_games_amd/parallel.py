@@ -1,0 +1,97 @@
+"""Env sharding across the GPUs of one node.
+
+Envs are independent (the reference runs them in separate Ray workers, run_scripts/train_moa.py:127-128),
+so the data path needs NO collective: rank r owns the contiguous global env indices
+[start_r, start_r + count_r) and steps them with its own engine on its own GPU.  PRNG keys derive
+from the GLOBAL env index (ssd_config.env_index_base), so results do not depend on how many GPUs
+the batch is split over.  Only when a caller asks for one batched tensor is there communication:
+an RCCL all-gather / gather of the uint8 observations, rewards and dones over xGMI -- each peer
+has a direct link to the root, so this is one hop, no ring.
+
+One process per GPU, `torch.distributed` (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+"""
+import os
+
+
+def shard_range(num_envs_total, world_size, rank):
+    """(start, count) of rank's contiguous block; the first (total % world) ranks get one extra env."""
+    if not (0 <= rank < world_size) or num_envs_total < 0:
+        raise ValueError("bad shard request")
+    base, extra = divmod(num_envs_total, world_size)
+    count = base + (1 if rank < extra else 0)
+    start = rank * base + min(rank, extra)
+    return start, count
+
+
+def init_process_group(backend=None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them).
+    Returns (dist, rank, world_size, local_rank); dist is None for a single process."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return None, 0, 1, local_rank
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        kw["device_id"] = torch.device("cuda", local_rank)
+    if not dist.is_initialized():
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist, rank, world, local_rank
+
+
+def make_sharded_engine(game, ascii_map, num_envs_total, num_agents, rank, world_size, local_rank=None, **kw):
+    """This rank's VecEngine over its block of the global batch."""
+    from .engine import VecEngine
+    start, count = shard_range(num_envs_total, world_size, rank)
+    dev = rank if local_rank is None else local_rank
+    eng = VecEngine(game, ascii_map, num_envs=count, num_agents=num_agents, env_index_base=start, device=dev, **kw)
+    return eng, start, count
+
+
+def all_gather_batch(dist, tensor, num_envs_total, world_size):
+    """Concatenate the per-rank shards of `tensor` ([count_r, ...]) along dim 0 on EVERY rank.
+
+    Equal shards go out as one all_gather_into_tensor (a single RCCL all-gather); ragged splits are
+    padded to the largest shard and trimmed after the collective."""
+    import torch
+    if dist is None or world_size == 1:
+        return tensor
+    counts = [shard_range(num_envs_total, world_size, r)[1] for r in range(world_size)]
+    tail = tuple(tensor.shape[1:])
+    if len(set(counts)) == 1:
+        out = torch.empty((num_envs_total,) + tail, dtype=tensor.dtype, device=tensor.device)
+        dist.all_gather_into_tensor(out, tensor.contiguous())
+        return out
+    mx = max(counts)
+    padded = torch.zeros((mx,) + tail, dtype=tensor.dtype, device=tensor.device)
+    padded[:tensor.shape[0]] = tensor
+    buf = torch.empty((world_size * mx,) + tail, dtype=tensor.dtype, device=tensor.device)
+    dist.all_gather_into_tensor(buf, padded)
+    return torch.cat([buf[r * mx:r * mx + counts[r]] for r in range(world_size)], dim=0)
+
+
+def gather_batch(dist, tensor, num_envs_total, world_size, rank, dst=0):
+    """As all_gather_batch but only rank `dst` receives the batch (others get None): the root ingests
+    the 7 peers' shards over its 7 direct xGMI links in parallel."""
+    import torch
+    if dist is None or world_size == 1:
+        return tensor
+    counts = [shard_range(num_envs_total, world_size, r)[1] for r in range(world_size)]
+    tail = tuple(tensor.shape[1:])
+    mx = max(counts)
+    padded = tensor.contiguous()
+    if tensor.shape[0] != mx:
+        padded = torch.zeros((mx,) + tail, dtype=tensor.dtype, device=tensor.device)
+        padded[:tensor.shape[0]] = tensor
+    bufs = [torch.empty((mx,) + tail, dtype=tensor.dtype, device=tensor.device) for _ in range(world_size)] \
+        if rank == dst else None
+    dist.gather(padded, gather_list=bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([bufs[r][:counts[r]] for r in range(world_size)], dim=0)

@@ -1,0 +1,82 @@
+"""N > 1 path on CPU: two gloo ranks shard a batch of envs by global index, step their shards and
+gather; the result must equal one process stepping the whole batch.  The stepping itself is done by
+the C oracle here (the product's engine needs a GPU); what is under test is the product's sharding,
+global-index seeding contract and gather helpers (sequential_social_dilemma_games_amd/parallel.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import golden_util as G
+from oracle import pyoracle
+from sequential_social_dilemma_games_amd import constants as K
+from sequential_social_dilemma_games_amd import parallel
+
+
+def test_shard_ranges_cover_the_batch_exactly():
+    for total in (0, 1, 7, 8, 4096, 32768, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+            for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+                assert s0 + c0 == s1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    assert parallel.shard_range(32768, 8, 3) == (3 * 4096, 4096)
+    with pytest.raises(ValueError):
+        parallel.shard_range(8, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, total, game, n_agents, steps, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist, r, w, _ = parallel.init_process_group("gloo")
+    amap = K.HARVEST_MAP if game == K.GAME_HARVEST else K.CLEANUP_MAP
+    start, count = parallel.shard_range(total, w, r)
+    ora = pyoracle.Oracle(game, amap, max(count, 1), n_agents, G.default_lut(), seed=77, env_base=start)
+    obs = ora.reset()[:count]
+    out = []
+    for _ in range(steps):
+        _, obs, rew, done = ora.step_random()
+        full_obs = parallel.all_gather_batch(dist, torch.from_numpy(obs[:count].copy()), total, w)
+        full_rew = parallel.gather_batch(dist, torch.from_numpy(rew[:count].copy()), total, w, r, dst=0)
+        if r == 0:
+            out.append((full_obs.numpy().copy(), full_rew.numpy().copy()))
+        else:
+            assert full_rew is None and full_obs.shape[0] == total
+    dist.barrier()
+    if r == 0:
+        q.put(out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,game", [(16, K.GAME_HARVEST), (13, K.GAME_CLEANUP)])
+def test_two_rank_shards_equal_one_process(total, game):
+    world, steps, n_agents = 2, 4, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, game, n_agents, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    amap = K.HARVEST_MAP if game == K.GAME_HARVEST else K.CLEANUP_MAP
+    ref = pyoracle.Oracle(game, amap, total, n_agents, G.default_lut(), seed=77, env_base=0)
+    ref.reset()
+    for s in range(steps):
+        _, obs, rew, _ = ref.step_random()
+        np.testing.assert_array_equal(got[s][0], obs, err_msg="obs step %d" % s)
+        np.testing.assert_array_equal(got[s][1], rew, err_msg="rew step %d" % s)
