@@ -20,7 +20,7 @@
  *   order   u8  [E,N]   agent indices in action-dict order, 0xFF-terminated; NULL = index order
  *   obs     u8  [E,N,V,V,3]   RGB; the reference's float64 obs is (u8 - 128.0) / 255.0
  *   rew     i32 [E,N]
- *   done    u8  [E,N]   always 0 (agent.py:174-175,209-210)
+ *   done    u8  [E,N]   0 (agent.py:174-175,209-210) unless a horizon is set (ssd_set_horizon)
  */
 #ifndef SSD_H
 #define SSD_H
@@ -121,6 +121,12 @@ int ssd_get_waste_count(ssd_env *env, uint32_t *waste_count);
 
 /* MapEnv.map_to_colors() on the full grid of env e (map_env.py:316-339): rgb u8 [H,W,3], host pointer. */
 int ssd_render_full(ssd_env *env, int32_t e, uint8_t *rgb);
+
+/* Episode length.  The reference's agents never report done; episodes end through RLlib's `horizon`
+ * (run_scripts/train_baseline.py:131, train_moa.py:122).  horizon > 0: a step whose t reaches it writes
+ * done = 1 for that env's agents (the caller then resets those envs, e.g. ssd_reset with done as the mask);
+ * 0 (default): done stays 0. */
+int ssd_set_horizon(ssd_env *env, int32_t horizon);
 
 /* Queries. */
 int ssd_potential_waste_area(const ssd_env *env);             /* cleanup.py:36-38 */

@@ -432,6 +432,12 @@ int ssd_render_full(ssd_env *env, int32_t e, uint8_t *rgb) {
     return SSD_OK;
 }
 
+int ssd_set_horizon(ssd_env *env, int32_t horizon) {
+    if (!env || horizon < 0) return SSD_E_INVALID;
+    env->p.horizon = horizon;
+    return SSD_OK;
+}
+
 int ssd_potential_waste_area(const ssd_env *env) { return env ? env->potential_waste : SSD_E_INVALID; }
 
 int ssd_device_status(ssd_env *env, uint32_t *status, int clear) {

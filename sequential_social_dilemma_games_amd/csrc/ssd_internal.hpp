@@ -24,6 +24,7 @@ struct Params {
     int32_t E, N, H, W, S;         // S = H*W rounded up to 16 (per-env stride of the grids in HBM)
     int32_t view_len, V, beam_len;
     int32_t mode, rotate, keep_beams, num_actions_random;
+    int32_t horizon;               // > 0: done = (t >= horizon), RLlib's `horizon` (train_baseline.py:131); 0: never done
     uint32_t w_magic;              // floor(2^32 / W) + 1 : cell / W for cell < 2^16
     uint32_t v_magic16;            // ceil(2^16 / V): pp / V == (pp * v_magic16) >> 16 for pp < V*V, V <= 31
     uint32_t seed_lo, seed_hi, env_base;

@@ -565,7 +565,8 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
                 p.agents[(size_t)e * N + lane] = cell | (orient << 16);
                 if (mode == kModeStep) {
                     if (p.rew) p.rew[(size_t)e * N + lane] = rew;                   // compute_reward (:208)
-                    if (p.done) p.done[(size_t)e * N + lane] = 0;                   // get_done -> False (:209)
+                    // get_done -> False (:209); with a horizon set, the episode ends after `horizon` steps
+                    if (p.done) p.done[(size_t)e * N + lane] = (p.horizon > 0 && t >= (uint32_t)p.horizon) ? 1 : 0;
                 }
             }
             if (lane == 0) p.hdr[e] = make_uint4(key, t, episode, waste_count);

@@ -192,6 +192,11 @@ class VecEngine(object):
         _capi.check(self._L.ssd_set_state(self._h, _ptr(world), _ptr(beam), _ptr(pos), _ptr(orient), _ptr(episode),
                                           _ptr(t)), self._h)
 
+    def set_horizon(self, horizon):
+        """done = (t >= horizon) from now on (RLlib's `horizon`, train_baseline.py:131); 0 = never (reference envs)."""
+        _capi.check(self._L.ssd_set_horizon(self._h, int(horizon)), self._h)
+        self.horizon = int(horizon)
+
     def waste_count(self):
         """u32 [E]: the number of 'H' cells the last step / reset computed the Cleanup spawn probabilities from."""
         out = np.zeros(self.E, np.uint32)
