@@ -64,6 +64,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries write to fd 1 behind Python's back (RCCL prints a
+    # version banner when the first communicator is created), so park the real stdout and point fd 1 at
+    # stderr for the rest of the run.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     from sequential_social_dilemma_games_amd import constants as K
     from sequential_social_dilemma_games_amd.engine import VecEngine
@@ -89,7 +96,7 @@ def main():
                                                      local_rank=local_rank, seed=0)
     assert (start, count) == (rank * E, E)
     out = eng.alloc_outputs()
-    do_gather = bool(args.gather and dist is not None)
+    do_gather = bool(args.gather and dist is not None and world >= 1)
 
     def one_step(k):
         if k % HORIZON == 0:
@@ -152,7 +159,8 @@ def main():
             res["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 PMC, same workload)"
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(game, amap, n_agents)
-        print(json.dumps(res))
+        print(json.dumps(res), file=real_stdout)
+        real_stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

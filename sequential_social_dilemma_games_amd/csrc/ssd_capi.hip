@@ -238,7 +238,11 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
     p.n_spawn = (int)spawn_cells.size(); p.n_thr = n_thr;
     p.n_apple = (int)apple_cells.size(); p.n_waste = (int)waste_cells.size();
     const double sp[4] = {0, 0.005, 0.02, 0.05};   // harvest.py:13 SPAWN_PROB
-    for (int i = 0; i < 4; ++i) p.thr_h[i] = cfg->harvest_thresholds ? cfg->harvest_thresholds[i] : threshold(sp[i]);
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t T = cfg->harvest_thresholds ? cfg->harvest_thresholds[i] : threshold(sp[i]);
+        p.thr_h32[i] = T >= 4294967296ull ? 0xFFFFFFFFu : (uint32_t)T;
+        if (T >= 4294967296ull) p.thr_h_always |= 1u << i;
+    }
 
     auto bail = [&](int rc) {
         g_create_error = env->err;

@@ -43,7 +43,8 @@ struct Params {
     const uint32_t *lut;           // [128]   r | g << 8 | b << 16
     const uint64_t *thr_ca;        // [n_thr] Cleanup apple thresholds by #'H'
     const uint64_t *thr_cw;        // [n_thr] Cleanup waste thresholds by #'H'
-    uint64_t thr_h[4];             // Harvest apple thresholds by min(#neighbour apples, 3)
+    uint32_t thr_h32[4];           // Harvest apple thresholds by min(#neighbour apples, 3): rand < p  <=>  u32 draw < thr
+    uint32_t thr_h_always;         // bit n set: threshold n is 2^32 (p >= 1), the compare always succeeds
     // per-call I/O (device pointers; any may be null)
     const int32_t *actions;        // [E][N]
     const uint8_t *order;          // [E][N]

@@ -151,7 +151,10 @@ __host__ size_t lds_bytes(int S) { return (size_t)kEnvsPerBlock * (128 * 4 + 3 *
 template <int GAME, int MODE>
 __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
     extern __shared__ __align__(16) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index and everything derived from it (env index, LDS region, global offsets) is wave-uniform:
+    // say so, and the per-env address arithmetic runs on the scalar unit instead of as 64-bit VALU multiplies
+    const int wv = (int)rfl((uint32_t)tid >> 6);
     const int S = p.S, N = p.N, W = p.W, H = p.H;
     uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + (size_t)wv * (512 + 3 * (size_t)S));
     uint8_t *s_world = reinterpret_cast<uint8_t *>(s_lut + 128);
@@ -476,17 +479,23 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
             if (GAME == 0) {
                 // harvest.py:75-104 spawn_apples.  Apple points are interior cells (the border is wall),
                 // so the 3x3 neighbourhood (j*j + k*k <= 2 on the radius-2 box, :90-92) is always in bounds.
+                // Threshold by neighbour count as a sum of steps on n >= k.  (An `n == 0 ? a : n == 1 ? b : ...`
+                // chain is turned into a switch lookup table by the compiler: an indexed vector load from the
+                // kernarg buffer in memory -- an L2 round trip per list entry on the critical path.)
+                const uint32_t t0 = p.thr_h32[0], d1 = p.thr_h32[1] - t0, d2 = p.thr_h32[2] - p.thr_h32[1],
+                               d3 = p.thr_h32[3] - p.thr_h32[2];
                 auto body = [&](int j, uint32_t c, bool valid) {
                     c = valid ? c : safe;
                     const uint8_t w = s_world[c], o = s_occ[c];
-                    int n = 0;
+                    uint32_t n = 0;
 #pragma unroll
                     for (int dr = -1; dr <= 1; ++dr)
 #pragma unroll
                         for (int dc = -1; dc <= 1; ++dc)
                             if (dr != 0 || dc != 0) n += s_world[(int)c + dr * W + dc] == 'A';
-                    const uint64_t thr = n == 0 ? p.thr_h[0] : n == 1 ? p.thr_h[1] : n == 2 ? p.thr_h[2] : p.thr_h[3];   // :100
-                    const bool hit = valid && w != 'A' && o == 0 && (uint64_t)draw(pk_apple, c) < thr;   // :88, :101-103
+                    const uint32_t thr = t0 + (n >= 1 ? d1 : 0u) + (n >= 2 ? d2 : 0u) + (n >= 3 ? d3 : 0u);   // :100 SPAWN_PROB[min(n, 3)]
+                    const bool always = ((p.thr_h_always >> (n < 3 ? n : 3u)) & 1u) != 0;
+                    const bool hit = valid & (w != 'A') & (o == 0) & ((draw(pk_apple, c) < thr) | always);   // :88, :101-103
                     spawn_bits |= hit ? bit(j) : 0ull;
                 };
                 // the first kListRegs list entries of every lane are processed without branches (a lane past the

@@ -25,12 +25,14 @@ def shard_range(num_envs_total, world_size, rank):
 
 def init_process_group(backend=None):
     """Join the job described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them).
-    Returns (dist, rank, world_size, local_rank); dist is None for a single process."""
+    Returns (dist, rank, world_size, local_rank); dist is None for a plain single process.  Under
+    torch.distributed.run the group is created even for one rank, so the RCCL path is the same code at
+    every world size."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
-        return None, 0, 1, local_rank
+    if world == 1 and "MASTER_PORT" not in os.environ:
+        return None, 0, 1, local_rank            # plain `python bench.py`: no process group at all
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

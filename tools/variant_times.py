@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Launch-time of the kernel's modes at E envs (GPU box): step with / without observation output,
+observe only, reset only.  Separates the per-launch floor from the phases."""
+import ctypes as C
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch  # noqa: E402
+from sequential_social_dilemma_games_amd import constants as K  # noqa: E402
+from sequential_social_dilemma_games_amd.engine import VecEngine  # noqa: E402
+
+
+def timeit(fn, n=2000):
+    for _ in range(200):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / n
+
+
+def main():
+    E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    game = K.GAME_CLEANUP if (len(sys.argv) > 2 and sys.argv[2] == "cleanup") else K.GAME_HARVEST
+    eng = VecEngine(game, None, num_envs=E, num_agents=5, seed=0)
+    obs, rew, done = eng.alloc_outputs()
+    eng.reset(obs=obs)
+    L, h, st = eng._L, eng._h, eng._stream()
+    dp = eng._dp
+    print("E=%d %s" % (E, "cleanup" if game else "harvest"))
+    print("  step_random, obs+rew+done : %6.2f us" % timeit(lambda: L.ssd_step_random(h, eng.num_actions, None, dp(obs), dp(rew), dp(done), 0, st)))
+    print("  step_random, no obs       : %6.2f us" % timeit(lambda: L.ssd_step_random(h, eng.num_actions, None, None, dp(rew), dp(done), 0, st)))
+    print("  step_random, no outputs   : %6.2f us" % timeit(lambda: L.ssd_step_random(h, eng.num_actions, None, None, None, None, 0, st)))
+    print("  observe only              : %6.2f us" % timeit(lambda: L.ssd_observe(h, dp(obs), 0, st)))
+    print("  reset, obs                : %6.2f us" % timeit(lambda: L.ssd_reset(h, None, dp(obs), 0, st)))
+    print("  reset, no obs             : %6.2f us" % timeit(lambda: L.ssd_reset(h, None, None, 0, st)))
+    x = torch.zeros(1, device="cuda")
+    print("  torch x.add_(1) (launch floor of a trivial kernel): %6.2f us" % timeit(lambda: x.add_(1)))
+
+
+if __name__ == "__main__":
+    main()
