@@ -255,6 +255,11 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
     if ((rc = dev_alloc(env, &p.world, (size_t)E * S))) return bail(rc);
     if (env->keep_beams) { if ((rc = dev_alloc(env, &p.beam, (size_t)E * S))) return bail(rc); }
     if ((rc = dev_alloc(env, &p.agents, (size_t)E * N))) return bail(rc);
+    if (N > 0) {   // before the first reset every agent sits on interior cell (1,1), facing UP: stepping an env that
+                   // was never reset is then well defined and cannot index outside the grid
+        std::vector<uint32_t> ag((size_t)E * N, (uint32_t)(W + 1) | (2u << 16));
+        if (hipMemcpy(p.agents, ag.data(), ag.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { env->err = "hipMemcpy(agents)"; return bail(SSD_E_DEVICE); }
+    }
     if ((rc = dev_alloc(env, &p.status, 1))) return bail(rc);
     {   // header: episode = 0xFFFFFFFF ("never reset"; the first reset wraps it to 0)
         std::vector<uint4> hdr(E);
@@ -396,7 +401,8 @@ int ssd_set_state(ssd_env *env, const int8_t *world, const int8_t *beam, const i
             uint32_t cell = ag[i] & 0xFFFFu, o = (ag[i] >> 16) & 3u;
             if (pos) {
                 const int r = pos[2 * i], c = pos[2 * i + 1];
-                if (r < 0 || r >= H || c < 0 || c >= W) { env->err = "agent position outside the map"; return SSD_E_INVALID; }
+                // agents live strictly inside the wall border; a position on the border could step out of the grid
+                if (r < 1 || r >= H - 1 || c < 1 || c >= W - 1) { env->err = "agent position must be inside the map's wall border"; return SSD_E_INVALID; }
                 cell = (uint32_t)(r * W + c);
             }
             if (orient) { if (orient[i] > 3) { env->err = "orientation code must be 0..3"; return SSD_E_INVALID; } o = orient[i]; }

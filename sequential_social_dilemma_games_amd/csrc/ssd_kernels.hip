@@ -15,9 +15,12 @@
 //     cells of the 15 x 15 window = 12 contiguous bytes per store, so a wavefront store covers up to
 //     768 contiguous bytes of the uint8 obs tensor (map_env.py:189-199);
 //   * waves never touch each other's LDS: the kernel has no workgroup barrier.
-// The kernel is latency-bound (4 waves per SIMD at 4096 envs), so cross-lane reductions use DPP /
-// scalar loops instead of LDS-crossbar shuffles, and LDS reads are issued in independent batches.
-// No MFMA: the path is integer / indexing work bounded by HBM traffic.
+// At 4096 envs (4 waves per SIMD) a launch lasts about as long as ONE wave's instruction stream plus
+// launch and store-drain time, so the code minimises a single wave's dynamic
+// instruction count and wait chain: every global load is issued in the prologue, cross-lane reductions
+// use DPP / scalar loops instead of LDS-crossbar shuffles, per-map work lists replace grid scans, and the
+// common conflict-free move takes a short path.
+// No MFMA: the path is integer / indexing work; its roofline is HBM traffic (4 724 B per env-step).
 //
 // Reference citations are file:line of the reference repository (social_dilemmas/envs/...).
 #include <hip/hip_runtime.h>

@@ -219,3 +219,50 @@ def test_vector_env_base_env_style_dicts():
     assert (venv.engine.get_state()["t"] == 0).all()
     first = venv.try_reset(1)
     assert first['agent-1'].shape == (15, 15, 3)
+
+
+def test_large_cleanup_map_with_active_spawning_exercises_long_cell_lists():
+    """Synthetic 48x36 Cleanup (412 apple points, 476 waste cells: more than the 192 list entries a wave keeps
+    in registers).  Random rollouts there never clean below the 0.4 density threshold, so most waste is removed
+    by hand first: apple and waste respawn then run on the long lists, against the oracle at every step."""
+    amap = K.cleanup_map_48x36()
+    E, N = 24, 10
+    eng = VecEngine(K.GAME_CLEANUP, amap, num_envs=E, num_agents=N, seed=21, keep_beams=True)
+    ora = pyoracle.Oracle(K.GAME_CLEANUP, amap, E, N, G.default_lut(), seed=21)
+    eng.reset_host(); ora.reset()
+    world = ora.get_state()["world"].copy()
+    rng = np.random.RandomState(5)
+    for e in range(E):
+        hs = np.argwhere(world[e] == ord('H'))
+        keep = rng.rand(len(hs)) < (0.02 + 0.03 * e)            # densities from ~0.01 to ~0.35 across envs
+        for (r, c), k in zip(hs, keep):
+            if not k:
+                world[e, r, c] = ord('R')
+    eng.set_state(world=world); ora.set_state(world=world)
+    spawned_a = spawned_h = 0
+    for s in range(60):
+        act, obs, rew, _ = eng.step_random_host()
+        o_act, o_obs, o_rew, _ = ora.step_random()
+        a, b = eng.get_state(), ora.get_state()
+        np.testing.assert_array_equal(a["world"], b["world"], err_msg="world step %d" % s)
+        np.testing.assert_array_equal(obs, o_obs, err_msg="obs step %d" % s)
+        np.testing.assert_array_equal(rew, o_rew)
+        spawned_a += int(((a["world"] == ord('A')) & (world != ord('A'))).sum())
+        spawned_h += int(((a["world"] == ord('H')) & (world != ord('H'))).sum())
+        world = a["world"].copy()
+    assert spawned_a > 200 and spawned_h > 100, (spawned_a, spawned_h)
+    # apples appeared in the second half of the apple list and waste in the second half of the waste list
+    cells_a = np.argwhere(np.array([[ch == 'B' for ch in row] for row in amap]))
+    late = cells_a[300:]
+    assert (world[:, late[:, 0], late[:, 1]] == ord('A')).any()
+    assert eng.status() == 0
+
+
+def test_stepping_before_reset_and_border_positions_are_safe():
+    eng = VecEngine(K.GAME_HARVEST, None, num_envs=8, num_agents=5, seed=1)
+    obs, rew, done = eng.step_random_host()[1:]                 # never reset: agents sit on (1,1), world is blank
+    st = eng.get_state()
+    assert (st["pos"] >= 0).all() and (st["pos"][..., 0] < 16).all() and (st["pos"][..., 1] < 38).all()
+    bad = st["pos"].copy(); bad[0, 0] = [0, 5]
+    with pytest.raises(Exception):
+        eng.set_state(pos=bad)
