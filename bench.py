@@ -96,15 +96,19 @@ def main():
                                                      local_rank=local_rank, seed=0)
     assert (start, count) == (rank * E, E)
     out = eng.alloc_outputs()
-    do_gather = bool(args.gather and dist is not None and world >= 1)
+    do_gather = bool(args.gather and dist is not None)
+    gbuf = None
+    if do_gather:                                  # the single batched tensors every rank ends up with
+        gbuf = (torch.empty((world * E,) + tuple(out[0].shape[1:]), dtype=torch.uint8, device=out[0].device),
+                torch.empty((world * E,) + tuple(out[1].shape[1:]), dtype=torch.int32, device=out[1].device))
 
     def one_step(k):
         if k % HORIZON == 0:
             eng.reset(obs=out[0])
         eng.step_random(out=out)
         if do_gather:                              # one batched tensor on every rank: RCCL all-gather over xGMI
-            parallel.all_gather_batch(dist, out[0], world * E, world)
-            parallel.all_gather_batch(dist, out[1], world * E, world)
+            parallel.all_gather_batch(dist, out[0], world * E, world, out=gbuf[0])
+            parallel.all_gather_batch(dist, out[1], world * E, world, out=gbuf[1])
 
     for k in range(args.warmup):
         one_step(k)

@@ -56,18 +56,20 @@ def make_sharded_engine(game, ascii_map, num_envs_total, num_agents, rank, world
     return eng, start, count
 
 
-def all_gather_batch(dist, tensor, num_envs_total, world_size):
+def all_gather_batch(dist, tensor, num_envs_total, world_size, out=None):
     """Concatenate the per-rank shards of `tensor` ([count_r, ...]) along dim 0 on EVERY rank.
 
-    Equal shards go out as one all_gather_into_tensor (a single RCCL all-gather); ragged splits are
-    padded to the largest shard and trimmed after the collective."""
+    Equal shards go out as one all_gather_into_tensor (a single RCCL all-gather) into `out` (preallocated
+    [num_envs_total, ...] buffer, optional); ragged splits are padded to the largest shard and trimmed after
+    the collective."""
     import torch
-    if dist is None or world_size == 1:
+    if dist is None:
         return tensor
     counts = [shard_range(num_envs_total, world_size, r)[1] for r in range(world_size)]
     tail = tuple(tensor.shape[1:])
     if len(set(counts)) == 1:
-        out = torch.empty((num_envs_total,) + tail, dtype=tensor.dtype, device=tensor.device)
+        if out is None:
+            out = torch.empty((num_envs_total,) + tail, dtype=tensor.dtype, device=tensor.device)
         dist.all_gather_into_tensor(out, tensor.contiguous())
         return out
     mx = max(counts)
@@ -82,7 +84,7 @@ def gather_batch(dist, tensor, num_envs_total, world_size, rank, dst=0):
     """As all_gather_batch but only rank `dst` receives the batch (others get None): the root ingests
     the 7 peers' shards over its 7 direct xGMI links in parallel."""
     import torch
-    if dist is None or world_size == 1:
+    if dist is None:
         return tensor
     counts = [shard_range(num_envs_total, world_size, r)[1] for r in range(world_size)]
     tail = tuple(tensor.shape[1:])
