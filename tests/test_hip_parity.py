@@ -266,3 +266,83 @@ def test_stepping_before_reset_and_border_positions_are_safe():
     bad = st["pos"].copy(); bad[0, 0] = [0, 5]
     with pytest.raises(Exception):
         eng.set_state(pos=bad)
+
+
+def _random_map(rng, H, W, game, n_spawn):
+    """Wall-closed random map with interior walls, apple / waste / river / stream cells and spawn points."""
+    g = np.full((H, W), ' ', dtype='<U1')
+    g[0, :] = g[-1, :] = '@'; g[:, 0] = g[:, -1] = '@'
+    inner = [(r, c) for r in range(1, H - 1) for c in range(1, W - 1)]
+    rng.shuffle(inner)
+    k = 0
+    for r, c in inner[k:k + n_spawn]:
+        g[r, c] = 'P'
+    k += n_spawn
+    n = len(inner)
+    for ch, frac in (('@', 0.06), ('A' if game == K.GAME_HARVEST else 'B', 0.25)) + \
+            ((('H', 0.10), ('R', 0.12), ('S', 0.03)) if game == K.GAME_CLEANUP else ()):
+        m = int(frac * n)
+        for r, c in inner[k:k + m]:
+            g[r, c] = ch
+        k += m
+    return ["".join(row) for row in g]
+
+
+UNUSUAL = [
+    # game, H, W, E, N, view_len, beam_len, steps
+    (K.GAME_HARVEST, 12, 14, 37, 64, 3, 5, 25),      # 64 agents: every lane of the wave is an agent
+    (K.GAME_CLEANUP, 12, 14, 37, 33, 2, 7, 25),
+    (K.GAME_HARVEST, 64, 64, 5, 20, 7, 5, 20),       # largest supported map (4096 cells)
+    (K.GAME_CLEANUP, 64, 64, 5, 20, 7, 3, 20),
+    (K.GAME_HARVEST, 9, 40, 130, 4, 15, 21, 25),     # widest view (31 x 31) and longest beam
+    (K.GAME_CLEANUP, 40, 9, 130, 4, 0, 1, 25),       # 1 x 1 view, beam of one cell
+    (K.GAME_CLEANUP, 20, 20, 64, 7, 7, 5, 60),
+]
+
+
+@pytest.mark.parametrize("case", range(len(UNUSUAL)))
+def test_unusual_configurations_match_the_oracle(case):
+    game, H, W, E, N, v, L, steps = UNUSUAL[case]
+    rng = np.random.RandomState(100 + case)
+    amap = _random_map(rng, H, W, game, n_spawn=N + 3)
+    eng = VecEngine(game, amap, num_envs=E, num_agents=N, view_len=v, beam_len=L, seed=case, keep_beams=True)
+    ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), view_len=v, beam_len=L, seed=case)
+    np.testing.assert_array_equal(eng.reset_host(), ora.reset())
+    if game == K.GAME_CLEANUP:                       # thin the waste out so that spawning is active in most envs
+        world = ora.get_state()["world"].copy()
+        hs = np.argwhere(world == ord('H'))
+        drop = rng.rand(len(hs)) < 0.8
+        world[hs[drop, 0], hs[drop, 1], hs[drop, 2]] = ord('R')
+        eng.set_state(world=world); ora.set_state(world=world)
+    for s in range(steps):
+        if s % 3 == 2:                               # explicit random orders / subsets every third step
+            act = rng.randint(0, 8 if game == K.GAME_HARVEST else 9, size=(E, N)).astype(np.int32)
+            order = np.full((E, N), 0xFF, np.uint8)
+            for e in range(E):
+                k = rng.randint(0, N + 1)
+                perm = rng.permutation(N)[:k]
+                order[e, :k] = perm
+                act[e, np.setdiff1d(np.arange(N), perm)] = -1
+            obs, rew, _ = eng.step_host(act, order)
+            o_obs, o_rew, _ = ora.step(act, order)
+        else:
+            _, obs, rew, _ = eng.step_random_host()
+            _, o_obs, o_rew, _ = ora.step_random()
+        np.testing.assert_array_equal(rew, o_rew, err_msg="rewards step %d" % s)
+        np.testing.assert_array_equal(obs, o_obs, err_msg="obs step %d" % s)
+        a, b = eng.get_state(), ora.get_state()
+        for key in ("world", "beam", "pos", "orient"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg="%s step %d" % (key, s))
+    assert eng.status() == 0
+
+
+def test_limits_are_rejected_with_messages():
+    from sequential_social_dilemma_games_amd import _capi
+    wall = ['@' * 66] + ['@' + ' ' * 64 + '@'] * 64 + ['@' * 66]
+    for kw, needle in ((dict(ascii_map=wall), "4096 cells"), (dict(num_agents=65), "num_agents"),
+                       (dict(view_len=16), "view_len"), (dict(beam_len=22), "beam_len")):
+        args = dict(game=K.GAME_HARVEST, ascii_map=None, num_envs=1, num_agents=1)
+        args.update(kw)
+        with pytest.raises(_capi.SsdError) as ei:
+            VecEngine(**args)
+        assert needle in str(ei.value), str(ei.value)
