@@ -304,7 +304,8 @@ int ssd_reset(ssd_env *env, const uint8_t *env_mask, uint8_t *obs, uint32_t flag
 
 int ssd_step(ssd_env *env, const int32_t *actions, const uint8_t *order, uint8_t *obs, int32_t *rew, uint8_t *done,
              uint32_t flags, void *stream) {
-    if (!env || !actions) { if (env) env->err = "actions is null"; return SSD_E_INVALID; }
+    if (!env) return SSD_E_INVALID;
+    if (!actions && env->N > 0) { env->err = "actions is null"; return SSD_E_INVALID; }   // an env without agents has no actions
     return run(env, ssd::kModeStep, actions, order, nullptr, 0, nullptr, obs, rew, done, 1, flags, stream);
 }
 
