@@ -461,6 +461,11 @@ int ssd_device_status(ssd_env *env, uint32_t *status, int clear) {
 }
 
 #ifdef SSD_STAMPS
+int ssd_debug_set_skip(ssd_env *env, uint32_t mask) {
+    if (!env) return SSD_E_INVALID;
+    env->p.dbg_skip = mask;
+    return SSD_OK;
+}
 // Diagnostic library only (make stamps): device buffer [E][16] u64 that the kernel fills with cycle stamps.
 int ssd_debug_set_stamps(ssd_env *env, void *dev_ptr) {
     if (!env) return SSD_E_INVALID;

@@ -53,6 +53,7 @@ struct Params {
     uint8_t *obs;                  // [E][N][V][V][3]
     int32_t *rew;                  // [E][N]
     uint8_t *done;                 // [E][N]
+    uint32_t dbg_skip;             // diagnostic builds (-DSSD_STAMPS) only: bit mask of phases to skip (tools/variant_times.py)
     unsigned long long *stamps;    // [E][16] s_memtime stamps; diagnostic builds (-DSSD_STAMPS) only, else null
 };
 

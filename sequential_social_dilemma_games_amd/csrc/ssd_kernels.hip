@@ -141,8 +141,10 @@ __device__ __forceinline__ uint32_t count_bytes_eq(uint32_t x, uint32_t ch) {
     do {                                                                                           \
         if (p.stamps && lane == 0 && e < p.E) p.stamps[(size_t)e * 16 + (i)] = __builtin_readcyclecounter(); \
     } while (0)
+#define SSD_SKIP(bit) ((p.dbg_skip >> (bit)) & 1u)
 #else
 #define SSD_STAMP(i)
+#define SSD_SKIP(bit) false
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
             }
 
             // ---- update_moves (map_env.py:357-543) ----
-            const bool mover = is_agent && act >= 0 && act <= 4;              // :383
+            const bool mover = !SSD_SKIP(0) && is_agent && act >= 0 && act <= 4;              // :383
             if (is_agent && (act == 5 || act == 6)) orient = turn(act, orient);   // :390-392
             uint32_t tcell = cell;
             if (mover) {
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
         }
 
         SSD_STAMP(2);   // moves resolved
-        if (mode != kModeReset) {
+        if (mode != kModeReset && !SSD_SKIP(1)) {
             // ---- consume (map_env.py:178-181, agent.py:177-183) + occupancy layer ----
             // Index order means: of several agents on one cell the LOWEST index eats the apple, and
             // agent_by_pos / the overlay show the HIGHEST index (:289-297, :603).
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
             const int L = p.beam_len;
             const uint32_t rmask = (1u << L) - 1u;
             constexpr int kFire = 7, kClean = 8;
-            uint64_t shooters = ballot(is_agent && (act == kFire || (GAME == 1 && act == kClean)));
+            uint64_t shooters = SSD_SKIP(2) ? 0ull : ballot(is_agent && (act == kFire || (GAME == 1 && act == kClean)));
             for (int k = 0; shooters && k < nord; ++k) {
                 const uint32_t a = rl(ordv, k);
                 if (!((shooters >> a) & 1)) continue;
@@ -479,6 +481,7 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
             const uint32_t safe = (uint32_t)(W + 1);                                // cell (1,1)
             uint32_t waste_cell = 0xFFFFFFFFu;
             uint32_t waste_count = 0;                                               // #'H' the probabilities were computed from
+            if (!SSD_SKIP(3)) {
             if (GAME == 0) {
                 // harvest.py:75-104 spawn_apples.  Apple points are interior cells (the border is wall),
                 // so the 3x3 neighbourhood (j*j + k*k <= 2 on the radius-2 box, :90-92) is always in bounds.
@@ -555,6 +558,7 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
                     uint32_t oh, ol;
                     if (wave_argmin_pair(has, bh, bl, oh, ol)) waste_cell = ol;
                 }
+            }
             }
             wave_sync();                                                            // counts use the pre-spawn map (harvest.py:73)
 #pragma unroll

@@ -40,6 +40,18 @@ def main():
     print("  observe only              : %6.2f us" % timeit(lambda: L.ssd_observe(h, dp(obs), 0, st)))
     print("  reset, obs                : %6.2f us" % timeit(lambda: L.ssd_reset(h, None, dp(obs), 0, st)))
     print("  reset, no obs             : %6.2f us" % timeit(lambda: L.ssd_reset(h, None, None, 0, st)))
+    if hasattr(L, "ssd_debug_set_skip") or os.environ.get("SSD_LIB_PATH", "").endswith("stamps.so"):
+        L.ssd_debug_set_skip.argtypes = [C.c_void_p, C.c_uint32]
+        full = timeit(lambda: L.ssd_step_random(h, eng.num_actions, None, dp(obs), dp(rew), dp(done), 0, st))
+        print("  marginal cost of a phase = full step (%.2f us) - step with the phase skipped:" % full)
+        for bit, name in enumerate(("move", "consume+occupancy", "beams", "respawn")):
+            L.ssd_debug_set_skip(h, 1 << bit)
+            t = timeit(lambda: L.ssd_step_random(h, eng.num_actions, None, dp(obs), dp(rew), dp(done), 0, st))
+            print("    %-18s %5.2f us" % (name, full - t))
+        L.ssd_debug_set_skip(h, 0xF)
+        t = timeit(lambda: L.ssd_step_random(h, eng.num_actions, None, None, dp(rew), dp(done), 0, st))
+        print("    all four + no obs: step costs %.2f us (load + write-back + launch floor)" % t)
+        L.ssd_debug_set_skip(h, 0)
     x = torch.zeros(1, device="cuda")
     print("  torch x.add_(1) (launch floor of a trivial kernel): %6.2f us" % timeit(lambda: x.add_(1)))
 
