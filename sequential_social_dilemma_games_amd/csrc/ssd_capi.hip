@@ -251,7 +251,7 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
         return rc;
     };
     int rc;
-    if (ssd::lds_bytes(S) > 64 * 1024) { env->err = "map too large for the 64 KiB LDS budget"; return bail(SSD_E_INVALID); }
+    if (ssd::lds_bytes(S, 1) > 64 * 1024) { env->err = "map too large for the 64 KiB LDS budget"; return bail(SSD_E_INVALID); }
     if ((rc = dev_alloc(env, &p.world, (size_t)E * S))) return bail(rc);
     if (env->keep_beams) { if ((rc = dev_alloc(env, &p.beam, (size_t)E * S))) return bail(rc); }
     if ((rc = dev_alloc(env, &p.agents, (size_t)E * N))) return bail(rc);

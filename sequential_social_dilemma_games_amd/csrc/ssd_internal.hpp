@@ -5,7 +5,7 @@
 namespace ssd {
 
 constexpr int kWave = 64;          // CDNA wavefront width
-constexpr int kEnvsPerBlock = 4;   // one wavefront per env, 4 envs per 256-thread workgroup
+constexpr int kMaxEnvsPerBlock = 16; // one wavefront per env; a workgroup holds 1..16 envs (chosen per launch, see launch())
 constexpr int kMaxAgents = 64;     // lanes = agents in the move / beam phases
 constexpr int kMaxCells = 4096;    // H*W, bounded by the u64 per-lane spawn bitmask and by LDS
 constexpr int kMaxBeamLen = 21;    // 3 rays * beam_len lanes must fit one wavefront
@@ -57,7 +57,8 @@ struct Params {
     unsigned long long *stamps;    // [E][16] s_memtime stamps; diagnostic builds (-DSSD_STAMPS) only, else null
 };
 
-size_t lds_bytes(int S);
+size_t lds_bytes(int S, int envs_per_block);
+int envs_per_block(int E, int S);
 void launch(const Params &p, int game, void *stream);
 void launch_render_full(const Params &p, int e, uint8_t *rgb_dev, void *stream);
 

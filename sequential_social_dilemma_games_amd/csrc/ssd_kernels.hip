@@ -25,6 +25,8 @@
 // Reference citations are file:line of the reference repository (social_dilemmas/envs/...).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "ssd_internal.hpp"
 
 namespace ssd {
@@ -34,7 +36,8 @@ constexpr uint32_t kStBadAction = 1u << 0;
 constexpr uint32_t kStNoSpawn = 1u << 1;
 constexpr uint32_t kStMoveLookup = 1u << 2;
 
-constexpr int kObsBatch = 5;       // agents rendered per pass of the observation phase
+constexpr int kObsBatch = 1;       // agents rendered per pass of the observation phase (1: each agent's store goes out as
+                                   // soon as it is ready, so the store drain overlaps the remaining agents; measured best)
 
 // ---------------------------------------------------------------------------------------------
 // shared PRNG (prng.py): triple32 chain
@@ -151,10 +154,27 @@ __device__ __forceinline__ uint32_t count_bytes_eq(uint32_t x, uint32_t ch) {
 // LDS layout of one workgroup: per wave (= per env)  lut[128] u32 | world[S] | beam[S] | occ[S]
 // Waves never read each other's LDS, so the kernel has no workgroup barrier.
 // ---------------------------------------------------------------------------------------------
-__host__ size_t lds_bytes(int S) { return (size_t)kEnvsPerBlock * (128 * 4 + 3 * (size_t)S); }
+__host__ size_t lds_bytes(int S, int envs_per_block) { return (size_t)envs_per_block * (128 * 4 + 3 * (size_t)S); }
+
+// Envs (= waves) per workgroup.  Waves are independent, so this only changes dispatch granularity; measured on
+// MI355X (Harvest, us per launch):  E=4096: 14.45 / 14.42 / 14.34 / 14.24 for 2 / 4 / 8 / 16 per block;
+// E=8192: 21.9 / 22.0 / 21.7 / 22.8;  E=65536: 111 / 113 / 117 / 136.  So: big blocks while the whole batch is one
+// round with at most one block per CU (256 CUs), small blocks once CUs run several rounds, and never fewer than
+// 256 blocks when the batch is small.  SSD_ENVS_PER_BLOCK overrides (tuning).
+__host__ int envs_per_block(int E, int S) {
+    static const int forced = [] { const char *v = getenv("SSD_ENVS_PER_BLOCK"); return v ? atoi(v) : 0; }();
+    auto pow2floor = [](int x) { int p = 1; while (p * 2 <= x) p *= 2; return p; };
+    int fill = pow2floor(E / 256 > 0 ? E / 256 : 1);            // keep >= 256 blocks
+    int rounds = pow2floor(65536 / E > 2 ? 65536 / E : 2);      // 16 at 4096 envs, 8 at 8192, ... 2 from 32768 on
+    int epb = fill < rounds ? fill : rounds;
+    if (epb > kMaxEnvsPerBlock) epb = kMaxEnvsPerBlock;
+    if (forced >= 1 && forced <= kMaxEnvsPerBlock) epb = forced;
+    while (epb > 1 && lds_bytes(S, epb) > 64 * 1024) epb /= 2;
+    return epb;
+}
 
 template <int GAME, int MODE>
-__global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
+__global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Params p) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index and everything derived from it (env index, LDS region, global offsets) is wave-uniform:
@@ -170,7 +190,7 @@ __global__ __launch_bounds__(256) void ssd_env_kernel(const Params p) {
     // needs one.  Pin what the prologue needs into SGPRs here so that the loads go out as one batch.
     asm volatile("" ::"s"(p.hdr), "s"(p.agents), "s"(p.world), "s"(p.lut), "s"(p.apple_cells), "s"(p.obs),
                  "s"(p.actions), "s"(p.order), "s"(p.n_apple), "s"(p.num_actions_random), "s"(p.w_magic));
-    const int e = blockIdx.x * kEnvsPerBlock + wv;
+    const int e = blockIdx.x * (int)(blockDim.x >> 6) + wv;
     constexpr int mode = MODE;                               // compile-time: step / reset / observe
     bool active = e < p.E;                                   // wave-uniform
     if (active && mode == kModeReset && p.mask) active = p.mask[e] != 0;
@@ -732,8 +752,9 @@ static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipS
 }
 
 void launch(const Params &p, int game, void *stream) {
-    const dim3 grid((p.E + kEnvsPerBlock - 1) / kEnvsPerBlock), block(256);
-    const size_t lds = lds_bytes(p.S);
+    const int epb = envs_per_block(p.E, p.S);
+    const dim3 grid((p.E + epb - 1) / epb), block(64 * epb);
+    const size_t lds = lds_bytes(p.S, epb);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (game == 0) launch_game<0>(p, grid, block, lds, s);
     else launch_game<1>(p, grid, block, lds, s);
