@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=None)
     ap.add_argument("--gather", action="store_true", help="RCCL all-gather of obs/rew after every step")
+    ap.add_argument("--obs-f32", action="store_true", help="separate mode: the kernel writes float32 observations (4x the obs bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -95,7 +96,7 @@ def main():
     eng, start, count = parallel.make_sharded_engine(game, amap, world * E, n_agents, rank, world,
                                                      local_rank=local_rank, seed=0)
     assert (start, count) == (rank * E, E)
-    out = eng.alloc_outputs()
+    out = eng.alloc_outputs(float32=args.obs_f32)
     do_gather = bool(args.gather and dist is not None)
     gbuf = None
     if do_gather:                                  # the single batched tensors every rank ends up with
@@ -139,26 +140,28 @@ def main():
         total_agent_steps = float(E) * n_agents * args.steps * world
         value = total_agent_steps / wall
         bytes_env = eng.algorithmic_bytes_per_env_step()
+        if args.obs_f32:                           # the obs term becomes N * 2700 in this mode
+            bytes_env += n_agents * eng.V * eng.V * 3 * 3
         launch_us = dev_ms * 1e3 / args.steps      # average launch-to-launch duration of the step kernel on its stream
         achieved = bytes_env * E / (launch_us * 1e-6) / 1e9
         res = {
             "metric": "agent-env-steps/sec (random actions)", "value": value, "unit": "agent-env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.obs_f32 else "u8", "data": "synthetic",
             "config": {"workload": "%s %dx%d, %d agents, %d envs per GPU, uniform random actions, reset every %d steps"
                                    % (args.game, eng.H, eng.W, n_agents, E, HORIZON),
-                       "envs_per_gpu": E, "agents": n_agents, "obs": "uint8 [E,N,15,15,3]", "launches_per_step": 1,
+                       "envs_per_gpu": E, "agents": n_agents, "obs": ("float32" if args.obs_f32 else "uint8") + " [E,N,15,15,3]", "launches_per_step": 1,
                        "gather": do_gather, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "ssd::ssd_env_kernel<%d, 0>" % game, "bytes_per_env_step": bytes_env,
+                         "kernel": "ssd::ssd_env_kernel<%d, 0, %s>" % (game, "true" if args.obs_f32 else "false"), "bytes_per_env_step": bytes_env,
                          "avg_launch_us": launch_us},
         }
         # HBM bytes per launch from the PMC counters of the committed profile of this exact workload
         # (tools/profile_gpu.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE correction)
         tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
         tkey = {"harvest": "harvest_16x38_n5_e4096", "cleanup": "cleanup_25x18_n5_e4096"}.get(args.game)
-        if tkey and E == 4096 and args.agents is None and os.path.exists(tpath):
+        if tkey and E == 4096 and args.agents is None and not args.obs_f32 and os.path.exists(tpath):
             res["roofline"]["traffic"] = json.load(open(tpath))[tkey]["hbm_bytes_per_launch"]
             res["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 PMC, same workload)"
         if not args.no_cpu_baseline and world == 1:

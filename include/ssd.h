@@ -19,6 +19,8 @@
  *   actions i32 [E,N]   -1 = agent absent from the action dict this step
  *   order   u8  [E,N]   agent indices in action-dict order, 0xFF-terminated; NULL = index order
  *   obs     u8  [E,N,V,V,3]   RGB; the reference's float64 obs is (u8 - 128.0) / 255.0
+ *           f32 [E,N,V,V,3]   with SSD_OBS_F32: float32(that float64 value), i.e. the reference observation cast to
+ *                             its declared Box(dtype=float32) space (harvest.py:39-40), NHWC per agent
  *   rew     i32 [E,N]
  *   done    u8  [E,N]   0 (agent.py:174-175,209-210) unless a horizon is set (ssd_set_horizon)
  */
@@ -49,7 +51,9 @@ enum {
                                 and the call returns after the results have landed.  Without it
                                 they are device pointers on the handle's device and the call only
                                 enqueues work on `stream`. */
-    SSD_NO_ROTATE = 1u << 1  /* ssd_observe only: reset-form observation (map_env.py:239-240) */
+    SSD_NO_ROTATE = 1u << 1, /* ssd_observe only: reset-form observation (map_env.py:239-240) */
+    SSD_OBS_F32 = 1u << 2    /* obs points at float32 [E,N,V,V,3] instead of uint8: the normalisation of map_env.py:199
+                                fused into the kernel (4x the observation bytes; a separate, slower mode) */
 };
 
 /* bits of the device status word */
@@ -90,19 +94,19 @@ int ssd_destroy(ssd_env *env);
 
 /* MapEnv.reset (map_env.py:214-249) on the envs selected by env_mask (u8 [E], NULL = all; same memory
  * kind as obs).  obs may be NULL. */
-int ssd_reset(ssd_env *env, const uint8_t *env_mask, uint8_t *obs, uint32_t flags, void *stream);
+int ssd_reset(ssd_env *env, const uint8_t *env_mask, void *obs, uint32_t flags, void *stream);
 
 /* MapEnv.step (map_env.py:152-212) on every env.  obs / rew / done may be NULL. */
-int ssd_step(ssd_env *env, const int32_t *actions, const uint8_t *order, uint8_t *obs, int32_t *rew,
+int ssd_step(ssd_env *env, const int32_t *actions, const uint8_t *order, void *obs, int32_t *rew,
              uint8_t *done, uint32_t flags, void *stream);
 
 /* The random-action rollout step of rollout.py:62-70: actions are drawn on the device, uniformly over
  * Discrete(num_actions), from the ACTION stream; actions_out (i32 [E,N]) may be NULL. */
-int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, uint8_t *obs, int32_t *rew,
+int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, void *obs, int32_t *rew,
                     uint8_t *done, uint32_t flags, void *stream);
 
 /* Observation of the current state without stepping (the per-agent part of map_env.py:189-199). */
-int ssd_observe(ssd_env *env, uint8_t *obs, uint32_t flags, void *stream);
+int ssd_observe(ssd_env *env, void *obs, uint32_t flags, void *stream);
 
 /* State access (host pointers, synchronous; any pointer may be NULL).  Mirrors what the reference's tests
  * poke directly: world_map (map_env.py:85), beam_pos (:86), Agent.pos / .orientation (agent.py:37-38).

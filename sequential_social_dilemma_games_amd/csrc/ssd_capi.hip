@@ -27,6 +27,7 @@ struct ssd_env {
     std::vector<void *> allocs;
     // staging for SSD_HOST_PTRS
     int32_t *st_actions = nullptr, *st_rew = nullptr, *st_actions_out = nullptr;
+    float *st_obs_f32 = nullptr;
     uint8_t *st_order = nullptr, *st_obs = nullptr, *st_done = nullptr, *st_mask = nullptr, *st_rgb = nullptr;
     std::string err;
 };
@@ -89,7 +90,7 @@ int fail_create(const std::string &msg, int code) {
     return code;
 }
 
-size_t obs_bytes(const ssd_env *env) { return (size_t)env->E * env->N * env->V * env->V * 3; }
+size_t obs_bytes(const ssd_env *env, bool f32 = false) { return (size_t)env->E * env->N * env->V * env->V * 3 * (f32 ? 4 : 1); }
 
 int ensure_staging(ssd_env *env) {
     if (env->st_obs) return SSD_OK;
@@ -107,13 +108,15 @@ int ensure_staging(ssd_env *env) {
 
 // Runs one launch of the fused kernel with the per-call pointers filled in; handles host staging.
 int run(ssd_env *env, int mode, const int32_t *actions, const uint8_t *order, const uint8_t *mask,
-        int num_actions_random, int32_t *actions_out, uint8_t *obs, int32_t *rew, uint8_t *done, int rotate,
+        int num_actions_random, int32_t *actions_out, void *obs_v, int32_t *rew, uint8_t *done, int rotate,
         uint32_t flags, void *stream) {
     SSD_HIP(env, hipSetDevice(env->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t en = (size_t)env->E * env->N;
-    const bool host = (flags & SSD_HOST_PTRS) != 0;
+    const bool host = (flags & SSD_HOST_PTRS) != 0, f32 = (flags & SSD_OBS_F32) != 0;
+    uint8_t *obs = static_cast<uint8_t *>(obs_v);
     Params p = env->p;
+    p.obs_f32 = f32 ? 1 : 0;
     p.mode = mode; p.rotate = rotate; p.num_actions_random = num_actions_random;
     if (!host) {
         if (obs && (reinterpret_cast<uintptr_t>(obs) & 3u)) { env->err = "obs must be 4-byte aligned"; return SSD_E_INVALID; }
@@ -130,16 +133,17 @@ int run(ssd_env *env, int mode, const int32_t *actions, const uint8_t *order, co
     if (mask) { SSD_HIP(env, hipMemcpyAsync(env->st_mask, mask, (size_t)env->E, hipMemcpyHostToDevice, s)); p.mask = env->st_mask; }
     if (actions_out) p.actions_out = env->st_actions_out;
     if (obs) {
-        p.obs = env->st_obs;
+        if (f32 && !env->st_obs_f32) { if ((rc = dev_alloc(env, &env->st_obs_f32, obs_bytes(env) /* floats */))) return rc; }
+        p.obs = f32 ? reinterpret_cast<uint8_t *>(env->st_obs_f32) : env->st_obs;
         if (mask)   // rows of envs that are not reset must come back unchanged
-            SSD_HIP(env, hipMemcpyAsync(env->st_obs, obs, obs_bytes(env), hipMemcpyHostToDevice, s));
+            SSD_HIP(env, hipMemcpyAsync(p.obs, obs, obs_bytes(env, f32), hipMemcpyHostToDevice, s));
     }
     if (rew) p.rew = env->st_rew;
     if (done) p.done = env->st_done;
     ssd::launch(p, env->game, stream);
     SSD_HIP(env, hipGetLastError());
     if (actions_out) SSD_HIP(env, hipMemcpyAsync(actions_out, env->st_actions_out, en * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (obs) SSD_HIP(env, hipMemcpyAsync(obs, env->st_obs, obs_bytes(env), hipMemcpyDeviceToHost, s));
+    if (obs) SSD_HIP(env, hipMemcpyAsync(obs, p.obs, obs_bytes(env, f32), hipMemcpyDeviceToHost, s));
     if (rew) SSD_HIP(env, hipMemcpyAsync(rew, env->st_rew, en * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (done) SSD_HIP(env, hipMemcpyAsync(done, env->st_done, en, hipMemcpyDeviceToHost, s));
     SSD_HIP(env, hipStreamSynchronize(s));
@@ -251,7 +255,7 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
         return rc;
     };
     int rc;
-    if (ssd::lds_bytes(S, 1) > 64 * 1024) { env->err = "map too large for the 64 KiB LDS budget"; return bail(SSD_E_INVALID); }
+    if (ssd::lds_bytes(S, 1, true) > 64 * 1024) { env->err = "map too large for the 64 KiB LDS budget"; return bail(SSD_E_INVALID); }
     if ((rc = dev_alloc(env, &p.world, (size_t)E * S))) return bail(rc);
     if (env->keep_beams) { if ((rc = dev_alloc(env, &p.beam, (size_t)E * S))) return bail(rc); }
     if ((rc = dev_alloc(env, &p.agents, (size_t)E * N))) return bail(rc);
@@ -280,6 +284,13 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
     p.waste_cells = d16;
     if ((rc = upload(env, &d32, lut))) return bail(rc);
     p.lut = d32;
+    {   // float32 of the reference's float64 normalisation (map_env.py:199), one entry per byte value
+        std::vector<float> f32lut(256);
+        for (int x = 0; x < 256; ++x) f32lut[x] = (float)(((double)x - 128.0) / 255.0);
+        float *df;
+        if ((rc = upload(env, &df, f32lut))) return bail(rc);
+        p.f32lut = df;
+    }
     if ((rc = upload(env, &d64, thr_ca))) return bail(rc);
     p.thr_ca = d64;
     if ((rc = upload(env, &d64, thr_cw))) return bail(rc);
@@ -297,19 +308,19 @@ int ssd_destroy(ssd_env *env) {
     return SSD_OK;
 }
 
-int ssd_reset(ssd_env *env, const uint8_t *env_mask, uint8_t *obs, uint32_t flags, void *stream) {
+int ssd_reset(ssd_env *env, const uint8_t *env_mask, void *obs, uint32_t flags, void *stream) {
     if (!env) return SSD_E_INVALID;
     return run(env, ssd::kModeReset, nullptr, nullptr, env_mask, 0, nullptr, obs, nullptr, nullptr, /*rotate=*/0, flags, stream);
 }
 
-int ssd_step(ssd_env *env, const int32_t *actions, const uint8_t *order, uint8_t *obs, int32_t *rew, uint8_t *done,
+int ssd_step(ssd_env *env, const int32_t *actions, const uint8_t *order, void *obs, int32_t *rew, uint8_t *done,
              uint32_t flags, void *stream) {
     if (!env) return SSD_E_INVALID;
     if (!actions && env->N > 0) { env->err = "actions is null"; return SSD_E_INVALID; }   // an env without agents has no actions
     return run(env, ssd::kModeStep, actions, order, nullptr, 0, nullptr, obs, rew, done, 1, flags, stream);
 }
 
-int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, uint8_t *obs, int32_t *rew, uint8_t *done,
+int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, void *obs, int32_t *rew, uint8_t *done,
                     uint32_t flags, void *stream) {
     if (!env) return SSD_E_INVALID;
     const int na = env->game == SSD_GAME_HARVEST ? 8 : 9;
@@ -317,7 +328,7 @@ int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, uin
     return run(env, ssd::kModeStep, nullptr, nullptr, nullptr, num_actions, actions_out, obs, rew, done, 1, flags, stream);
 }
 
-int ssd_observe(ssd_env *env, uint8_t *obs, uint32_t flags, void *stream) {
+int ssd_observe(ssd_env *env, void *obs, uint32_t flags, void *stream) {
     if (!env || !obs) return SSD_E_INVALID;
     return run(env, ssd::kModeObserve, nullptr, nullptr, nullptr, 0, nullptr, obs, nullptr, nullptr,
                (flags & SSD_NO_ROTATE) ? 0 : 1, flags, stream);

@@ -24,6 +24,7 @@ struct Params {
     int32_t E, N, H, W, S;         // S = H*W rounded up to 16 (per-env stride of the grids in HBM)
     int32_t view_len, V, beam_len;
     int32_t mode, rotate, keep_beams, num_actions_random;
+    int32_t obs_f32;               // obs is float32 [E,N,V,V,3] (SSD_OBS_F32) instead of uint8
     int32_t horizon;               // > 0: done = (t >= horizon), RLlib's `horizon` (train_baseline.py:131); 0: never done
     uint32_t w_magic;              // floor(2^32 / W) + 1 : cell / W for cell < 2^16
     uint32_t v_magic16;            // ceil(2^16 / V): pp / V == (pp * v_magic16) >> 16 for pp < V*V, V <= 31
@@ -41,6 +42,7 @@ struct Params {
     const uint16_t *apple_cells;   // [n_apple] 'A' (harvest.py:22-26) / 'B' (cleanup.py:53-54) cells, row-major
     const uint16_t *waste_cells;   // [n_waste] 'H' or 'R' cells (cleanup.py:59-60), row-major
     const uint32_t *lut;           // [128]   r | g << 8 | b << 16
+    const float *f32lut;           // [256]   float32((x - 128.0) / 255.0), exact (host-built)
     const uint64_t *thr_ca;        // [n_thr] Cleanup apple thresholds by #'H'
     const uint64_t *thr_cw;        // [n_thr] Cleanup waste thresholds by #'H'
     uint32_t thr_h32[4];           // Harvest apple thresholds by min(#neighbour apples, 3): rand < p  <=>  u32 draw < thr
@@ -50,15 +52,15 @@ struct Params {
     const uint8_t *order;          // [E][N]
     const uint8_t *mask;           // [E]     reset only
     int32_t *actions_out;          // [E][N]
-    uint8_t *obs;                  // [E][N][V][V][3]
+    uint8_t *obs;                  // [E][N][V][V][3] u8, or float32 with obs_f32
     int32_t *rew;                  // [E][N]
     uint8_t *done;                 // [E][N]
     uint32_t dbg_skip;             // diagnostic builds (-DSSD_STAMPS) only: bit mask of phases to skip (tools/variant_times.py)
     unsigned long long *stamps;    // [E][16] s_memtime stamps; diagnostic builds (-DSSD_STAMPS) only, else null
 };
 
-size_t lds_bytes(int S, int envs_per_block);
-int envs_per_block(int E, int S);
+size_t lds_bytes(int S, int envs_per_block, bool f32);
+int envs_per_block(int E, int S, bool f32);
 void launch(const Params &p, int game, void *stream);
 void launch_render_full(const Params &p, int e, uint8_t *rgb_dev, void *stream);
 

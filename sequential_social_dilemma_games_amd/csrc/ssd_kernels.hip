@@ -151,17 +151,20 @@ __device__ __forceinline__ uint32_t count_bytes_eq(uint32_t x, uint32_t ch) {
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// LDS layout of one workgroup: per wave (= per env)  lut[128] u32 | world[S] | beam[S] | occ[S]
+// LDS layout of one workgroup: per wave (= per env)  lut[128] u32 | f32lut[256] (float32-obs kernels only) |
+// world[S] | beam[S] | occ[S]
 // Waves never read each other's LDS, so the kernel has no workgroup barrier.
 // ---------------------------------------------------------------------------------------------
-__host__ size_t lds_bytes(int S, int envs_per_block) { return (size_t)envs_per_block * (128 * 4 + 3 * (size_t)S); }
+__host__ size_t lds_bytes(int S, int envs_per_block, bool f32) {
+    return (size_t)envs_per_block * (128 * 4 + (f32 ? 256 * 4 : 0) + 3 * (size_t)S);
+}
 
 // Envs (= waves) per workgroup.  Waves are independent, so this only changes dispatch granularity; measured on
 // MI355X (Harvest, us per launch):  E=4096: 14.45 / 14.42 / 14.34 / 14.24 for 2 / 4 / 8 / 16 per block;
 // E=8192: 21.9 / 22.0 / 21.7 / 22.8;  E=65536: 111 / 113 / 117 / 136.  So: big blocks while the whole batch is one
 // round with at most one block per CU (256 CUs), small blocks once CUs run several rounds, and never fewer than
 // 256 blocks when the batch is small.  SSD_ENVS_PER_BLOCK overrides (tuning).
-__host__ int envs_per_block(int E, int S) {
+__host__ int envs_per_block(int E, int S, bool f32) {
     static const int forced = [] { const char *v = getenv("SSD_ENVS_PER_BLOCK"); return v ? atoi(v) : 0; }();
     auto pow2floor = [](int x) { int p = 1; while (p * 2 <= x) p *= 2; return p; };
     int fill = pow2floor(E / 256 > 0 ? E / 256 : 1);            // keep >= 256 blocks
@@ -169,11 +172,11 @@ __host__ int envs_per_block(int E, int S) {
     int epb = fill < rounds ? fill : rounds;
     if (epb > kMaxEnvsPerBlock) epb = kMaxEnvsPerBlock;
     if (forced >= 1 && forced <= kMaxEnvsPerBlock) epb = forced;
-    while (epb > 1 && lds_bytes(S, epb) > 64 * 1024) epb /= 2;
+    while (epb > 1 && lds_bytes(S, epb, f32) > 64 * 1024) epb /= 2;
     return epb;
 }
 
-template <int GAME, int MODE>
+template <int GAME, int MODE, bool F32>
 __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Params p) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -181,8 +184,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
     // say so, and the per-env address arithmetic runs on the scalar unit instead of as 64-bit VALU multiplies
     const int wv = (int)rfl((uint32_t)tid >> 6);
     const int S = p.S, N = p.N, W = p.W, H = p.H;
-    uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + (size_t)wv * (512 + 3 * (size_t)S));
-    uint8_t *s_world = reinterpret_cast<uint8_t *>(s_lut + 128);
+    uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + (size_t)wv * (512 + (F32 ? 1024 : 0) + 3 * (size_t)S));
+    float *s_f32 = reinterpret_cast<float *>(s_lut + 128);          // float32-observation kernels only
+    uint8_t *s_world = reinterpret_cast<uint8_t *>(s_lut + 128 + (F32 ? 256 : 0));
     uint8_t *s_beam = s_world + S;
     uint8_t *s_occ = s_beam + S;
 
@@ -218,6 +222,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
         }
         // glyph -> RGB table of the observation phase, one copy per wave
         const uint32_t lut_a = p.obs ? p.lut[lane] : 0u, lut_b = p.obs ? p.lut[lane + 64] : 0u;
+        const bool obs_f32 = F32 && p.obs;
+        float4 flut = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (obs_f32) flut = reinterpret_cast<const float4 *>(p.f32lut)[lane];
         // static cell lists of the map: the first 64*kListRegs entries live in registers
         uint32_t alist[kListRegs], wlist[kListRegs];
 #pragma unroll
@@ -228,6 +235,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
         }
         uint32_t key = rfl(hdr.x), t = rfl(hdr.y), episode = rfl(hdr.z);
         s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b;
+        if (obs_f32) reinterpret_cast<float4 *>(s_f32)[lane] = flut;
         uint32_t status = 0;
         uint32_t cell = areg & 0xFFFFu, orient = mode == kModeReset ? 2u : (areg >> 16) & 3u;   // lane = agent index
         int rew = 0;
@@ -703,7 +711,34 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
 #pragma unroll
                     for (int u = 0; u < kObsBatch; ++u) {
                         if (ag0 + u >= N) break;
-                        uint8_t *dst = out_env + ((size_t)(ag0 + u) * VV + pp0) * 3;
+                        const size_t cell0 = (size_t)(ag0 + u) * VV + pp0;         // first of this lane's cells within the env
+                        if (obs_f32) {
+                            // float32 mode: 3 floats per cell through the exact byte -> float table, 48 contiguous
+                            // bytes per lane (three 16-byte stores; an agent block starts at a multiple of 2700 B)
+                            float *dstf = reinterpret_cast<float *>(p.obs) + ((size_t)e * N * VV + cell0) * 3;
+                            float f[12];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                f[q * 3 + 0] = s_f32[px[u][q] & 0xFFu];
+                                f[q * 3 + 1] = s_f32[(px[u][q] >> 8) & 0xFFu];
+                                f[q * 3 + 2] = s_f32[(px[u][q] >> 16) & 0xFFu];
+                            }
+                            if (ncell >= 4) {
+                                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                                struct __attribute__((packed, aligned(4))) F4 { f32x4 v; };
+#pragma unroll
+                                for (int k4 = 0; k4 < 3; ++k4) {
+                                    f32x4 v4 = {f[4 * k4], f[4 * k4 + 1], f[4 * k4 + 2], f[4 * k4 + 3]};
+                                    reinterpret_cast<F4 *>(dstf + 4 * k4)->v = v4;
+                                }
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 3; ++q)
+                                    if (q < ncell) { dstf[q * 3] = f[q * 3]; dstf[q * 3 + 1] = f[q * 3 + 1]; dstf[q * 3 + 2] = f[q * 3 + 2]; }
+                            }
+                            continue;
+                        }
+                        uint8_t *dst = out_env + cell0 * 3;
                         if (ncell >= 4) {
                             typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
                             struct __attribute__((packed, aligned(1))) P3 { u32x3 v; };
@@ -742,22 +777,23 @@ __global__ void ssd_render_full_kernel(const Params p, int e, uint8_t *rgb) {
     }
 }
 
-template <int GAME>
+template <int GAME, bool F32>
 static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
     switch (p.mode) {
-    case kModeStep: hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStep>), grid, block, lds, s, p); break;
-    case kModeReset: hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeReset>), grid, block, lds, s, p); break;
-    default: hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeObserve>), grid, block, lds, s, p); break;
+    case kModeStep: hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStep, F32>), grid, block, lds, s, p); break;
+    case kModeReset: hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeReset, F32>), grid, block, lds, s, p); break;
+    default: hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeObserve, F32>), grid, block, lds, s, p); break;
     }
 }
 
 void launch(const Params &p, int game, void *stream) {
-    const int epb = envs_per_block(p.E, p.S);
+    const bool f32 = p.obs && p.obs_f32;            // the float32-observation variant is a separate instantiation
+    const int epb = envs_per_block(p.E, p.S, f32);
     const dim3 grid((p.E + epb - 1) / epb), block(64 * epb);
-    const size_t lds = lds_bytes(p.S, epb);
+    const size_t lds = lds_bytes(p.S, epb, f32);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (game == 0) launch_game<0>(p, grid, block, lds, s);
-    else launch_game<1>(p, grid, block, lds, s);
+    if (game == 0) { if (f32) launch_game<0, true>(p, grid, block, lds, s); else launch_game<0, false>(p, grid, block, lds, s); }
+    else { if (f32) launch_game<1, true>(p, grid, block, lds, s); else launch_game<1, false>(p, grid, block, lds, s); }
 }
 
 void launch_render_full(const Params &p, int e, uint8_t *rgb_dev, void *stream) {

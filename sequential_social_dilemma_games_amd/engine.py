@@ -77,10 +77,10 @@ class VecEngine(object):
         torch, dev = self._torch()
         return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
-    def alloc_outputs(self):
-        """(obs u8 [E,N,V,V,3], rew i32 [E,N], done u8 [E,N]) on the engine's device."""
+    def alloc_outputs(self, float32=False):
+        """(obs u8 -- or float32 -- [E,N,V,V,3], rew i32 [E,N], done u8 [E,N]) on the engine's device."""
         torch, dev = self._torch()
-        return (torch.empty((self.E, self.N, self.V, self.V, 3), dtype=torch.uint8, device=dev),
+        return (torch.empty((self.E, self.N, self.V, self.V, 3), dtype=torch.float32 if float32 else torch.uint8, device=dev),
                 torch.empty((self.E, self.N), dtype=torch.int32, device=dev),
                 torch.empty((self.E, self.N), dtype=torch.uint8, device=dev))
 
@@ -93,16 +93,26 @@ class VecEngine(object):
         if t.device != dev or t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
             raise ValueError("%s must be a contiguous %s tensor of shape %s on %s" % (name, dtype, tuple(shape), dev))
 
+    def _obs_flags(self, obs):
+        """Observation buffers may be uint8 (default) or float32: float32((u8 - 128.0) / 255.0), written by the
+        kernel itself (SSD_OBS_F32) -- what the first layer of a policy network consumes."""
+        torch, dev = self._torch()
+        if obs is None:
+            return 0
+        if obs.dtype not in (torch.uint8, torch.float32):
+            raise ValueError("obs must be uint8 or float32")
+        self._check_tensor(obs, (self.E, self.N, self.V, self.V, 3), obs.dtype, "obs")
+        return _capi.SSD_OBS_F32 if obs.dtype == torch.float32 else 0
+
     def reset(self, mask=None, obs=None):
         """MapEnv.reset (map_env.py:214-249) for every env (or those with mask != 0).  Returns obs."""
         torch, dev = self._torch()
         if obs is None:
             obs = (torch.zeros if mask is not None else torch.empty)(
                 (self.E, self.N, self.V, self.V, 3), dtype=torch.uint8, device=dev)
-        self._check_tensor(obs, (self.E, self.N, self.V, self.V, 3), torch.uint8, "obs")
         if mask is not None:
             self._check_tensor(mask, (self.E,), torch.uint8, "mask")
-        _capi.check(self._L.ssd_reset(self._h, self._dp(mask), self._dp(obs), 0, self._stream()), self._h)
+        _capi.check(self._L.ssd_reset(self._h, self._dp(mask), self._dp(obs), self._obs_flags(obs), self._stream()), self._h)
         return obs
 
     def step(self, actions, order=None, out=None):
@@ -114,7 +124,7 @@ class VecEngine(object):
             self._check_tensor(order, (self.E, self.N), torch.uint8, "order")
         obs, rew, done = out if out is not None else self.alloc_outputs()
         _capi.check(self._L.ssd_step(self._h, self._dp(actions), self._dp(order), self._dp(obs), self._dp(rew),
-                                     self._dp(done), 0, self._stream()), self._h)
+                                     self._dp(done), self._obs_flags(obs), self._stream()), self._h)
         return obs, rew, done
 
     def step_random(self, out=None, actions_out=None, num_actions=None):
@@ -122,14 +132,14 @@ class VecEngine(object):
         obs, rew, done = out if out is not None else self.alloc_outputs()
         na = self.num_actions if num_actions is None else int(num_actions)
         _capi.check(self._L.ssd_step_random(self._h, na, self._dp(actions_out), self._dp(obs), self._dp(rew),
-                                            self._dp(done), 0, self._stream()), self._h)
+                                            self._dp(done), self._obs_flags(obs), self._stream()), self._h)
         return obs, rew, done
 
     def observe(self, rotate=True, obs=None):
         torch, dev = self._torch()
         if obs is None:
             obs = torch.empty((self.E, self.N, self.V, self.V, 3), dtype=torch.uint8, device=dev)
-        _capi.check(self._L.ssd_observe(self._h, self._dp(obs), 0 if rotate else _capi.SSD_NO_ROTATE,
+        _capi.check(self._L.ssd_observe(self._h, self._dp(obs), (0 if rotate else _capi.SSD_NO_ROTATE) | self._obs_flags(obs),
                                         self._stream()), self._h)
         return obs
 

@@ -23,10 +23,11 @@ _NORMALISE = (np.arange(256, dtype=np.float64) - 128.0) / 255.0
 
 class SSDVectorEnv(object):
     def __init__(self, game, num_envs, num_agents, horizon=1000, ascii_map=None, seed=0, device=0,
-                 env_index_base=0, view_len=K.VIEW_LEN):
+                 env_index_base=0, view_len=K.VIEW_LEN, float32_obs=False):
         self.engine = VecEngine(game, ascii_map, num_envs=num_envs, num_agents=num_agents, seed=seed, device=device,
                                 env_index_base=env_index_base, view_len=view_len)
         self.num_envs, self.num_agents, self.horizon = num_envs, num_agents, int(horizon)
+        self.float32_obs = bool(float32_obs)     # the kernel writes float32((u8 - 128) / 255) NHWC directly
         self.engine.set_horizon(self.horizon)
         self.agent_ids = ['agent-%d' % i for i in range(num_agents)]
         self._out = None
@@ -34,7 +35,7 @@ class SSDVectorEnv(object):
 
     # ------------------------------------------------------------------ tensor API
     def reset(self):
-        self._out = self.engine.alloc_outputs()
+        self._out = self.engine.alloc_outputs(float32=self.float32_obs)
         self.engine.reset(obs=self._out[0])
         return self._out[0]
 
@@ -58,7 +59,8 @@ class SSDVectorEnv(object):
     def to_float(obs):
         """uint8 [E,N,V,V,3] -> float32 NHWC batch [(E*N),V,V,3] with the reference's scaling
         ((x - 128) / 255, map_env.py:199), on the device: the input the first conv layer of
-        models/conv_to_fcnet_v2.py:33-56 expects."""
+        models/conv_to_fcnet_v2.py:33-56 expects.  With float32_obs=True the step
+        kernel writes this directly and no conversion pass is needed."""
         import torch
         E, N, V = obs.shape[0], obs.shape[1], obs.shape[2]
         return ((obs.to(torch.float32) - 128.0) / 255.0).reshape(E * N, V, V, 3)
@@ -66,6 +68,8 @@ class SSDVectorEnv(object):
     # ------------------------------------------------------------------ BaseEnv-style API
     def poll(self):
         """-> (obs, rewards, dones, infos, off_policy_actions) as {env_id: {agent_id: value}} dicts."""
+        if self.float32_obs:
+            raise RuntimeError("the dict surface renormalises uint8 observations: construct with float32_obs=False")
         if self._pending is None:
             obs = self.reset().cpu().numpy()
             rew = np.zeros((self.num_envs, self.num_agents), np.int32)
@@ -95,6 +99,6 @@ class SSDVectorEnv(object):
         mask = torch.zeros(self.num_envs, dtype=torch.uint8, device=torch.device("cuda", self.engine.device))
         mask[env_id] = 1
         if self._out is None:
-            self._out = self.engine.alloc_outputs()
+            self._out = self.engine.alloc_outputs(float32=self.float32_obs)
         self.engine.reset(mask=mask, obs=self._out[0])
         return {a: _NORMALISE[self._out[0][env_id, k].cpu().numpy()] for k, a in enumerate(self.agent_ids)}

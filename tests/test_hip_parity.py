@@ -346,3 +346,31 @@ def test_limits_are_rejected_with_messages():
         with pytest.raises(_capi.SsdError) as ei:
             VecEngine(**args)
         assert needle in str(ei.value), str(ei.value)
+
+
+def test_float32_observation_mode_is_the_cast_of_the_reference_float64():
+    """SSD_OBS_F32: the kernel writes float32((u8 - 128.0) / 255.0) -- the reference's float64 observation
+    (map_env.py:199) cast to its declared float32 space -- for step, reset and observe; bit-exact, ragged E."""
+    import torch
+    for game, E, N in ((K.GAME_HARVEST, 259, 5), (K.GAME_CLEANUP, 64, 10)):
+        a = VecEngine(game, None, num_envs=E, num_agents=N, seed=8, keep_beams=True)
+        b = VecEngine(game, None, num_envs=E, num_agents=N, seed=8, keep_beams=True)
+        fa = a.alloc_outputs(float32=True)
+        ub = b.alloc_outputs()
+
+        def same(f32, u8):
+            want = ((u8.cpu().numpy().astype(np.float64) - 128.0) / 255.0).astype(np.float32)
+            assert np.array_equal(f32.cpu().numpy(), want)
+
+        a.reset(obs=fa[0]); b.reset(obs=ub[0])
+        same(fa[0], ub[0])
+        for _ in range(12):
+            a.step_random(out=fa); b.step_random(out=ub)
+            same(fa[0], ub[0])
+            assert torch.equal(fa[1], ub[1])
+        same(a.observe(rotate=False, obs=torch.empty_like(fa[0])), b.observe(rotate=False))
+        mask = torch.from_numpy((np.arange(E) % 2).astype(np.uint8)).cuda()
+        before = fa[0].clone()
+        a.reset(mask=mask, obs=fa[0]); b.reset(mask=mask, obs=ub[0])
+        same(fa[0][mask.bool()], ub[0][mask.bool()])
+        assert torch.equal(fa[0][~mask.bool()], before[~mask.bool()])          # rows of envs that were not reset stay
