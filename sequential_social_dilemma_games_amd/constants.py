@@ -8,52 +8,24 @@ Cell alphabet of a world grid: ' ' empty, '@' wall, 'A' apple, 'H' waste, 'R' ri
 'B' (apple spawn point).  View-only glyphs: '1'..'9' agents, 'F'/'C' beams, '0' padding.
 """
 
-# 16 rows x 38 cols.  (BASELINE.json labels it "25x38"; no such map exists in the reference.)
-HARVEST_MAP = [
-    '@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@',
-    '@ P   P      A    P AAAAA    P  A P  @',
-    '@  P     A P AA    P    AAA    A  A  @',
-    '@     A AAA  AAA    A    A AA AAAA   @',
-    '@ A  AAA A    A  A AAA  A  A   A A   @',
-    '@AAA  A A    A  AAA A  AAA        A P@',
-    '@ A A  AAA  AAA  A A    A AA   AA AA @',
-    '@  A A  AAA    A A  AAA    AAA  A    @',
-    '@   AAA  A      AAA  A    AAAA       @',
-    '@ P  A       A  A AAA    A  A      P @',
-    '@A  AAA  A  A  AAA A    AAAA     P   @',
-    '@    A A   AAA  A A      A AA   A  P @',
-    '@     AAA   A A  AAA      AA   AAA P @',
-    '@ A    A     AAA  A  P          A    @',
-    '@       P     A         P  P P     P @',
-    '@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@']
+import os
 
-# 25 rows x 18 cols.
-CLEANUP_MAP = [
-    '@@@@@@@@@@@@@@@@@@',
-    '@RRRRRR     BBBBB@',
-    '@HHHHHH      BBBB@',
-    '@RRRRRR     BBBBB@',
-    '@RRRRR  P    BBBB@',
-    '@RRRRR    P BBBBB@',
-    '@HHHHH       BBBB@',
-    '@RRRRR      BBBBB@',
-    '@HHHHHHSSSSSSBBBB@',
-    '@HHHHHHSSSSSSBBBB@',
-    '@RRRRR   P P BBBB@',
-    '@HHHHH   P  BBBBB@',
-    '@RRRRRR    P BBBB@',
-    '@HHHHHH P   BBBBB@',
-    '@RRRRR       BBBB@',
-    '@HHHH    P  BBBBB@',
-    '@RRRRR       BBBB@',
-    '@HHHHH  P P BBBBB@',
-    '@RRRRR       BBBB@',
-    '@HHHH       BBBBB@',
-    '@RRRRR       BBBB@',
-    '@HHHHH      BBBBB@',
-    '@RRRRR       BBBB@',
-    '@HHHH       BBBBB@',
-    '@@@@@@@@@@@@@@@@@@']
+_MAPS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "maps")
+
+
+def load_map(name):
+    """ASCII map shipped as a data file under maps/ (one row per line)."""
+    with open(os.path.join(_MAPS, name + ".txt")) as f:
+        rows = [line.rstrip("\n") for line in f if line.strip("\n")]
+    if not rows or any(len(r) != len(rows[0]) for r in rows):
+        raise ValueError("map %s is not rectangular" % name)
+    return rows
+
+
+# The reference's two maps (data, social_dilemmas/constants.py:7-50): Harvest is 16 rows x 38 cols -- BASELINE.json
+# labels it "25x38", but no such map exists in the reference -- and Cleanup is 25 rows x 18 cols.
+HARVEST_MAP = load_map("harvest_16x38")
+CLEANUP_MAP = load_map("cleanup_25x18")
 
 
 def harvest_map_25x38():
