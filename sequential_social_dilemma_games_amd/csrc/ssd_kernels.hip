@@ -176,14 +176,19 @@ __host__ int envs_per_block(int E, int S, bool f32) {
     return epb;
 }
 
-template <int GAME, int MODE, bool F32>
+// NA > 0: the number of agents is the compile-time constant NA; STD: view_len 7 / beam_len 5, the reference's module
+// constants (harvest.py:11,15; cleanup.py:11-12,22).  Fixing them lets the compiler unroll the agent loops, fold the
+// window arithmetic and address agents' lanes by immediate: 14.3 -> 12.6 us per 4096-env step (N, V, L fixed).
+// NA = 0 / STD = false is the fully general kernel.
+template <int GAME, int MODE, bool F32, int NA, bool STD>
 __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Params p) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index and everything derived from it (env index, LDS region, global offsets) is wave-uniform:
     // say so, and the per-env address arithmetic runs on the scalar unit instead of as 64-bit VALU multiplies
     const int wv = (int)rfl((uint32_t)tid >> 6);
-    const int S = p.S, N = p.N, W = p.W, H = p.H;
+    const int S = p.S, W = p.W, H = p.H;
+    const int N = NA > 0 ? NA : p.N;
     uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + (size_t)wv * (512 + (F32 ? 1024 : 0) + 3 * (size_t)S));
     float *s_f32 = reinterpret_cast<float *>(s_lut + 128);          // float32-observation kernels only
     uint8_t *s_world = reinterpret_cast<uint8_t *>(s_lut + 128 + (F32 ? 256 : 0));
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
         SSD_STAMP(3);   // consume + occupancy
         if (mode == kModeStep) {
             // ---- update_custom_moves (map_env.py:545-552): beams in action order ----
-            const int L = p.beam_len;
+            const int L = STD ? 5 : p.beam_len;
             const uint32_t rmask = (1u << L) - 1u;
             constexpr int kFire = 7, kClean = 8;
             uint64_t shooters = SSD_SKIP(2) ? 0ull : ballot(is_agent && (act == kFire || (GAME == 1 && act == kClean)));
@@ -642,7 +647,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
         //      the 12-byte stores rely on gfx9's unaligned global access. ----
         if (p.obs) {
             typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-            const int V = p.V, v = p.view_len, VV = V * V;
+            const int V = STD ? 15 : p.V, v = STD ? 7 : p.view_len, VV = V * V;
             uint8_t *out_env = p.obs + (size_t)e * N * VV * 3;
             // Per-agent constants, computed once with lane = agent and read back as scalars in the loop.
             // Window cell (a, b) of an agent at (r0, c0) is grid cell (r0 - v + a, c0 - v + b); it is inside
@@ -670,7 +675,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int pp = pp0 + q;
-                    const int i = (int)(((uint32_t)pp * p.v_magic16) >> 16), j = pp - i * V;   // pp / V, pp % V
+                    const int i = STD ? pp / 15 : (int)(((uint32_t)pp * p.v_magic16) >> 16), j = pp - i * V;   // pp / V, pp % V
                     P0[q] = (uint32_t)i | ((uint32_t)j << 16);
                     P1[q] = (uint32_t)j | ((uint32_t)(V - 1 - i) << 16);
                     L0[q] = i * W + j;
@@ -777,12 +782,24 @@ __global__ void ssd_render_full_kernel(const Params p, int e, uint8_t *rgb) {
     }
 }
 
+template <int GAME, bool F32, int NA, bool STD>
+static void launch_step(const Params &p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStep, F32, NA, STD>), grid, block, lds, s, p);
+}
+
 template <int GAME, bool F32>
 static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-    switch (p.mode) {
-    case kModeStep: hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStep, F32>), grid, block, lds, s, p); break;
-    case kModeReset: hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeReset, F32>), grid, block, lds, s, p); break;
-    default: hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeObserve, F32>), grid, block, lds, s, p); break;
+    if (p.mode == kModeStep) {
+        // specialised step kernels for the reference's configurations (view 7, beam 5; 5 or 10 agents)
+        const bool std_view = p.view_len == 7 && p.beam_len == 5;
+        if (std_view && p.N == 5) launch_step<GAME, F32, 5, true>(p, grid, block, lds, s);
+        else if (std_view && p.N == 10) launch_step<GAME, F32, 10, true>(p, grid, block, lds, s);
+        else if (std_view) launch_step<GAME, F32, 0, true>(p, grid, block, lds, s);
+        else launch_step<GAME, F32, 0, false>(p, grid, block, lds, s);
+    } else if (p.mode == kModeReset) {
+        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeReset, F32, 0, false>), grid, block, lds, s, p);
+    } else {
+        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeObserve, F32, 0, false>), grid, block, lds, s, p);
     }
 }
 
