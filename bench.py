@@ -154,7 +154,7 @@ def main():
                        "gather": do_gather, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "ssd::ssd_env_kernel<%d, 0, %s>" % (game, "true" if args.obs_f32 else "false"), "bytes_per_env_step": bytes_env,
+                         "kernel": "ssd::ssd_env_kernel<%d, 0, %s, ...>" % (game, "true" if args.obs_f32 else "false"), "bytes_per_env_step": bytes_env,
                          "avg_launch_us": launch_us},
         }
         # HBM bytes per launch from the PMC counters of the committed profile of this exact workload
