@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Long-run parity soak (GPU box): E envs, T random-action steps with a reset every 1000 steps; every K steps the
+engine's full state (world, positions, orientations, counters) and the step's observations / rewards are compared
+with the C oracle's.  python tools/soak_parity.py [harvest|cleanup] [E] [T] [K]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import golden_util as G  # noqa: E402
+from oracle import pyoracle  # noqa: E402
+from sequential_social_dilemma_games_amd import constants as K  # noqa: E402
+from sequential_social_dilemma_games_amd.engine import VecEngine  # noqa: E402
+
+
+def main():
+    game = K.GAME_CLEANUP if (len(sys.argv) > 1 and sys.argv[1] == "cleanup") else K.GAME_HARVEST
+    E = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    T = int(sys.argv[3]) if len(sys.argv) > 3 else 4000
+    Kc = int(sys.argv[4]) if len(sys.argv) > 4 else 50
+    amap = K.HARVEST_MAP if game == K.GAME_HARVEST else K.CLEANUP_MAP
+    eng = VecEngine(game, amap, num_envs=E, num_agents=5, seed=2024)
+    ora = pyoracle.Oracle(game, amap, E, 5, G.default_lut(), seed=2024)
+    out = eng.alloc_outputs()
+    eng.reset(obs=out[0]); ora.reset()
+    t0 = time.time()
+    checks = 0
+    rsum = 0
+    for s in range(T):
+        if s and s % 1000 == 0:
+            eng.reset(obs=out[0]); ora.reset()
+        obs, rew, _ = eng.step_random(out=out)
+        want_obs = (s % Kc == Kc - 1)
+        _, o_obs, o_rew, _ = ora.step_random(want_obs=want_obs)
+        if want_obs:
+            r = rew.cpu().numpy()
+            assert np.array_equal(r, o_rew), "rewards differ at step %d" % s
+            assert np.array_equal(obs.cpu().numpy(), o_obs), "observations differ at step %d" % s
+            a, b = eng.get_state(), ora.get_state()
+            for k in ("world", "pos", "orient", "episode", "t"):
+                assert np.array_equal(a[k], b[k]), "%s differs at step %d" % (k, s)
+            checks += 1
+            rsum += int(r.sum())
+            if checks % 10 == 0:
+                print("step %6d ok (%d checkpoints, %.0f s)" % (s + 1, checks, time.time() - t0), flush=True)
+    assert eng.status() == 0
+    print("soak ok: %s, %d envs x %d steps = %.1f M env-steps, %d checkpoints bit-exact" %
+          ("cleanup" if game else "harvest", E, T, E * T / 1e6, checks))
+
+
+if __name__ == "__main__":
+    main()
