@@ -151,12 +151,12 @@ __device__ __forceinline__ uint32_t count_bytes_eq(uint32_t x, uint32_t ch) {
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// LDS layout of one workgroup: per wave (= per env)  lut[128] u32 | f32lut[256] (float32-obs kernels only) |
-// world[S] | beam[S] | occ[S]
+// LDS layout of one workgroup: per wave (= per env)  lut[128] u32 | scratch[64] u16 |
+// f32lut[256] (float32-obs kernels only) | world[S] | beam[S] | occ[S]
 // Waves never read each other's LDS, so the kernel has no workgroup barrier.
 // ---------------------------------------------------------------------------------------------
 __host__ size_t lds_bytes(int S, int envs_per_block, bool f32) {
-    return (size_t)envs_per_block * (128 * 4 + (f32 ? 256 * 4 : 0) + 3 * (size_t)S);
+    return (size_t)envs_per_block * (128 * 4 + 128 + (f32 ? 256 * 4 : 0) + 3 * (size_t)S);
 }
 
 // Envs (= waves) per workgroup.  Waves are independent, so this only changes dispatch granularity; measured on
@@ -193,9 +193,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
     const int S = FAST ? (GAME == 0 ? 608 : 464) : p.S;
     const int N = NA > 0 ? NA : p.N;
     const bool has_order = !FAST && p.order != nullptr, keep_beams = !FAST && p.keep_beams != 0;
-    uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + (size_t)wv * (512 + (F32 ? 1024 : 0) + 3 * (size_t)S));
-    float *s_f32 = reinterpret_cast<float *>(s_lut + 128);          // float32-observation kernels only
-    uint8_t *s_world = reinterpret_cast<uint8_t *>(s_lut + 128 + (F32 ? 256 : 0));
+    uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + (size_t)wv * (512 + 128 + (F32 ? 1024 : 0) + 3 * (size_t)S));
+    uint16_t *s_tmp = reinterpret_cast<uint16_t *>(s_lut + 128);    // 64 cells of scratch (respawn compaction)
+    float *s_f32 = reinterpret_cast<float *>(s_lut + 160);          // float32-observation kernels only
+    uint8_t *s_world = reinterpret_cast<uint8_t *>(s_lut + 160 + (F32 ? 256 : 0));
     uint8_t *s_beam = s_world + S;
     uint8_t *s_occ = s_beam + S;
 
@@ -527,27 +528,63 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 // kernarg buffer in memory -- an L2 round trip per list entry on the critical path.)
                 const uint32_t t0 = p.thr_h32[0], d1 = p.thr_h32[1] - t0, d2 = p.thr_h32[2] - p.thr_h32[1],
                                d3 = p.thr_h32[3] - p.thr_h32[2];
-                auto body = [&](int j, uint32_t c, bool valid) {
-                    c = valid ? c : safe;
-                    const uint8_t w = s_world[c], o = s_occ[c];
+                // 3x3 apple count, threshold and keyed draw of one candidate cell (:90-103)
+                auto wins = [&](uint32_t c) -> bool {
                     uint32_t n = 0;
 #pragma unroll
                     for (int dr = -1; dr <= 1; ++dr)
 #pragma unroll
                         for (int dc = -1; dc <= 1; ++dc)
                             if (dr != 0 || dc != 0) n += s_world[(int)c + dr * W + dc] == 'A';
-                    const uint32_t thr = t0 + (n >= 1 ? d1 : 0u) + (n >= 2 ? d2 : 0u) + (n >= 3 ? d3 : 0u);   // :100 SPAWN_PROB[min(n, 3)]
+                    const uint32_t thr = t0 + (n >= 1 ? d1 : 0u) + (n >= 2 ? d2 : 0u) + (n >= 3 ? d3 : 0u);   // SPAWN_PROB[min(n, 3)]
                     const bool always = ((p.thr_h_always >> (n < 3 ? n : 3u)) & 1u) != 0;
-                    const bool hit = valid & (w != 'A') & (o == 0) & ((draw(pk_apple, c) < thr) | always);   // :88, :101-103
-                    spawn_bits |= hit ? bit(j) : 0ull;
+                    return (draw(pk_apple, c) < thr) | always;
                 };
-                // the first kListRegs list entries of every lane are processed without branches (a lane past the
-                // end of the list is merely invalid), so their LDS reads are in flight together
+                // Pass 1 (cheap): which list entries are candidates at all -- an empty cell nobody stands on (:88).
+                bool el[kListRegs];
+                uint64_t em[kListRegs];
+                int total = 0;
 #pragma unroll
-                for (int j = 0; j < kListRegs; ++j) body(j, alist[j], lane + 64 * j < p.n_apple);
-                for (int j = kListRegs; j < a_iters; ++j) {
-                    const int idx = lane + 64 * j;
-                    body(j, idx < p.n_apple ? p.apple_cells[idx] : 0u, idx < p.n_apple);
+                for (int j = 0; j < kListRegs; ++j) {
+                    const bool valid = lane + 64 * j < p.n_apple;
+                    const uint32_t c = valid ? alist[j] : safe;
+                    el[j] = valid & (s_world[c] != 'A') & (s_occ[c] == 0);
+                    em[j] = ballot(el[j]);
+                    total += __builtin_popcountll(em[j]);
+                }
+                if (a_iters <= kListRegs && total <= 64) {
+                    // Usual case: at most 64 candidates among the (up to 192) apple points.  Compact them through
+                    // 128 B of LDS scratch so that ONE pass of lanes does the stencil + draw instead of three.
+                    if (total) {
+                        int base = 0;
+#pragma unroll
+                        for (int j = 0; j < kListRegs; ++j) {
+                            const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(em[j] >> 32),
+                                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)em[j], 0u));
+                            if (el[j]) s_tmp[slot] = (uint16_t)alist[j];
+                            base += __builtin_popcountll(em[j]);
+                        }
+                        wave_sync();
+                        const bool mine = lane < total;
+                        const uint32_t c = mine ? (uint32_t)s_tmp[lane] : safe;
+                        const bool hit = mine & wins(c);
+                        wave_sync();                                                // every count used the pre-spawn map (:73)
+                        if (hit) s_world[c] = 'A';
+                    }
+                } else {
+                    // general form: every lane evaluates its own list entries
+#pragma unroll
+                    for (int j = 0; j < kListRegs; ++j) {
+                        const uint32_t c = el[j] ? alist[j] : safe;
+                        spawn_bits |= (el[j] & wins(c)) ? bit(j) : 0ull;
+                    }
+                    for (int j = kListRegs; j < a_iters; ++j) {
+                        const int idx = lane + 64 * j;
+                        const bool valid = idx < p.n_apple;
+                        const uint32_t c = valid ? p.apple_cells[idx] : safe;
+                        const bool cand = valid & (s_world[c] != 'A') & (s_occ[c] == 0);
+                        spawn_bits |= (cand & wins(c)) ? bit(j) : 0ull;
+                    }
                 }
             } else {
                 // cleanup.py:113-116: compute_probabilities (:156-171) from the current waste count, then
