@@ -710,7 +710,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
             }
             const uint32_t pkv = (uint32_t)(V - 1) * 0x00010001u;
             for (int base = 0; base < VV; base += 256) {
-                const int pp0 = base + 4 * lane;
+                // A lane renders 4 consecutive cells = one 12-byte store.  V*V is not a multiple of 4 (225 = 56*4 + 1):
+                // the lane holding the leftover cells starts 4 cells before the end instead, re-rendering up to 3
+                // cells of its neighbour (same bytes, written twice) so that EVERY store is a full 12 bytes and the
+                // wave never takes a divergent byte-store path.  Views under 4 cells (view_len 0) use byte stores.
+                const int pp_raw = base + 4 * lane;
+                const bool lane_on = pp_raw < VV;
+                const int pp0 = (VV >= 4 && pp_raw > VV - 4) ? VV - 4 : pp_raw;
                 uint32_t P0[4], P1[4];
                 int L0[4], L1[4];
 #pragma unroll
@@ -722,7 +728,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                     L0[q] = i * W + j;
                     L1[q] = j * W + (V - 1 - i);
                 }
-                const int ncell = VV - pp0;                                         // >= 4: full group
+                const int ncell = lane_on ? VV - pp0 : 0;                           // >= 4 whenever VV >= 4
                 // kObsBatch agents per pass: all their grid reads go out together, then all LUT reads,
                 // then the stores (agents past N re-render agent N-1 and skip the store).
                 for (int ag0 = 0; ag0 < N; ag0 += kObsBatch) {
@@ -769,7 +775,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                                 f[q * 3 + 1] = s_f32[(px[u][q] >> 8) & 0xFFu];
                                 f[q * 3 + 2] = s_f32[(px[u][q] >> 16) & 0xFFu];
                             }
-                            if (ncell >= 4) {
+                            if (VV >= 4) {
+                              if (lane_on) {
                                 typedef float f32x4 __attribute__((ext_vector_type(4)));
                                 struct __attribute__((packed, aligned(4))) F4 { f32x4 v; };
 #pragma unroll
@@ -777,6 +784,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                                     f32x4 v4 = {f[4 * k4], f[4 * k4 + 1], f[4 * k4 + 2], f[4 * k4 + 3]};
                                     reinterpret_cast<F4 *>(dstf + 4 * k4)->v = v4;
                                 }
+                              }
                             } else {
 #pragma unroll
                                 for (int q = 0; q < 3; ++q)
@@ -785,7 +793,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                             continue;
                         }
                         uint8_t *dst = out_env + cell0 * 3;
-                        if (ncell >= 4) {
+                        if (VV >= 4) {
+                          if (lane_on) {
                             typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
                             struct __attribute__((packed, aligned(1))) P3 { u32x3 v; };
                             u32x3 d;
@@ -793,6 +802,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                             d.y = (px[u][1] >> 8) | (px[u][2] << 16);
                             d.z = (px[u][2] >> 16) | (px[u][3] << 8);
                             reinterpret_cast<P3 *>(dst)->v = d;
+                          }
                         } else {
 #pragma unroll
                             for (int q = 0; q < 3; ++q)
