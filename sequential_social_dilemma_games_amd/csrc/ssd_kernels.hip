@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
             bool clash = false;
             for (int j = 0; j < N; ++j) {
                 const uint32_t cj = rl(cell, j), tj = rl(tcell, j);
-                clash |= mover && j != lane && (tcell == cj || (((M >> j) & 1) && tcell == tj));
+                clash |= mover & (j != lane) & ((tcell == cj) | ((((M >> j) & 1) != 0) & (tcell == tj)));
             }
             const bool slow = ballot(clash) != 0;
             if (!slow) {
@@ -440,11 +440,12 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
             // agent_by_pos / the overlay show the HIGHEST index (:289-297, :603).
             bool lower = false, higher = false;
             for (int j = 0; j < N; ++j) {
-                const bool same = is_agent && rl(cell, j) == cell;
-                lower |= same && j < lane;
-                higher |= same && j > lane;
+                const bool same = is_agent & (rl(cell, j) == cell);     // bitwise on purpose: no short-circuit branches
+                lower |= same & (j < lane);
+                higher |= same & (j > lane);
             }
-            if (mode == kModeStep && is_agent && !lower && s_world[cell] == 'A') { s_world[cell] = ' '; rew += 1; }
+            const bool eats = (mode == kModeStep) & is_agent & !lower & (s_world[cell] == 'A');
+            if (eats) { s_world[cell] = ' '; rew += 1; }
             if (is_agent && !higher) s_occ[cell] = agent_glyph((uint32_t)lane);
             wave_sync();
         }
@@ -798,9 +799,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                             typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
                             struct __attribute__((packed, aligned(1))) P3 { u32x3 v; };
                             u32x3 d;
-                            d.x = px[u][0] | (px[u][1] << 24);
-                            d.y = (px[u][1] >> 8) | (px[u][2] << 16);
-                            d.z = (px[u][2] >> 16) | (px[u][3] << 8);
+                            // 4 x (r,g,b) -> 12 bytes with three byte permutes (v_perm_b32: selector bytes 0-3 pick from
+                            // the second operand, 4-7 from the first)
+                            d.x = __builtin_amdgcn_perm(px[u][1], px[u][0], 0x04020100u);   // r0 g0 b0 r1
+                            d.y = __builtin_amdgcn_perm(px[u][2], px[u][1], 0x05040201u);   // g1 b1 r2 g2
+                            d.z = __builtin_amdgcn_perm(px[u][3], px[u][2], 0x06050402u);   // b2 r3 g3 b3
                             reinterpret_cast<P3 *>(dst)->v = d;
                           }
                         } else {
