@@ -325,15 +325,15 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
             const bool mover = !SSD_SKIP(0) && is_agent && act >= 0 && act <= 4;              // :383
             if (is_agent && (act == 5 || act == 6)) orient = turn(act, orient);   // :390-392
             uint32_t tcell = cell;
-            if (mover) {
-                int vr, vc, dr, dc;
-                unit_vec(act, vr, vc);
+            {   // every lane runs this (non-movers get a zero step), so the wall read is one unconditional LDS load
+                int vr, vc;
+                unit_vec(mover ? act : 4, vr, vc);
                 // rotate_action (:701-716): UP (v) LEFT (vc,-vr) RIGHT (-vc,vr) DOWN (-v)
-                dr = orient == 2 ? vr : orient == 0 ? vc : orient == 1 ? -vc : -vr;
-                dc = orient == 2 ? vc : orient == 0 ? -vr : orient == 1 ? vr : -vc;
+                const int dr = orient == 2 ? vr : orient == 0 ? vc : orient == 1 ? -vc : -vr;
+                const int dc = orient == 2 ? vc : orient == 0 ? -vr : orient == 1 ? vr : -vc;
                 const uint32_t cand = (uint32_t)((int)cell + dr * W + dc);
                 // agent.py:105-113 return_valid_pos (the agent's grid agrees with world_map on '@')
-                tcell = s_world[cand] == '@' ? cell : cand;
+                tcell = (mover & (s_world[cand] != '@')) ? cand : cell;
             }
             uint32_t mvcell = tcell;                         // agent_moves[id] (:410)
             const uint64_t M = ballot(mover);
@@ -475,13 +475,14 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 const int sr = pr + (q == 1 ? rr - dr : q == 2 ? -rr - dr : 0);     // :608-609 start positions
                 const int sc = pcc + (q == 1 ? rc - dc : q == 2 ? -rc - dc : 0);
                 const int r2 = sr + dr * (kk + 1), c2 = sc + dc * (kk + 1);
-                const bool inb = inray && r2 >= 0 && r2 < H && c2 >= 0 && c2 < W;   // :615 test_if_in_bounds
+                const bool inb = inray & ((unsigned)r2 < (unsigned)H) & ((unsigned)c2 < (unsigned)W);   // :615 test_if_in_bounds
                 const int cidx = inb ? r2 * W + c2 : 0;
-                const uint8_t wch = inb ? s_world[cidx] : (uint8_t)'@';
-                const uint8_t och = inb ? s_occ[cidx] : (uint8_t)0;
-                const bool pass = inb && wch != '@';                                // :616
-                const bool stopper = pass && (och != 0 || (clean && wch == 'H'));   // :621 agents absorb, :639 blocking cell
-                const uint64_t mf = ballot(inray && !pass), ms = ballot(stopper);
+                const uint8_t wraw = s_world[cidx], oraw = s_occ[cidx];            // unconditional loads (cell 0 when out of the map)
+                const uint8_t wch = inb ? wraw : (uint8_t)'@';
+                const uint8_t och = inb ? oraw : (uint8_t)0;
+                const bool pass = inb & (wch != '@');                               // :616
+                const bool stopper = pass & ((och != 0) | (clean & (wch == 'H')));  // :621 agents absorb, :639 blocking cell
+                const uint64_t mf = ballot(inray & !pass), ms = ballot(stopper);
                 const uint32_t f = (uint32_t)(mf >> (q * L)) & rmask, s = (uint32_t)(ms >> (q * L)) & rmask;
                 const int ff = f ? __builtin_ctz(f) : L, fs = s ? __builtin_ctz(s) : L;
                 const int len = fs < ff ? fs + 1 : ff;                              // beam covers the stopping cell
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 auto apple = [&](int j, uint32_t c, bool valid) {                   // :135-141
                     c = valid ? c : safe;
                     const uint8_t w = s_world[c], o = s_occ[c];
-                    const bool hit = valid && w != 'A' && o == 0 && (uint64_t)draw(pk_apple, c) < thr_a;
+                    const bool hit = valid & (w != 'A') & (o == 0) & ((uint64_t)draw(pk_apple, c) < thr_a);
                     spawn_bits |= hit ? bit(j) : 0ull;
                 };
 #pragma unroll
@@ -619,9 +620,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                     uint32_t bh = 0, bl = 0;
                     auto waste = [&](uint32_t c, bool valid) {
                         c = valid ? c : safe;
-                        const bool cand = valid && s_world[c] != 'H' && (uint64_t)draw(pk_coin, c) < thr_w;
+                        const bool cand = valid & (s_world[c] != 'H') & ((uint64_t)draw(pk_coin, c) < thr_w);
                         const uint32_t kh = draw(pk_ord, c);
-                        if (cand && (!has || kh < bh || (kh == bh && c < bl))) { bh = kh; bl = c; has = true; }
+                        const bool better = cand & (!has | (kh < bh) | ((kh == bh) & (c < bl)));
+                        bh = better ? kh : bh; bl = better ? c : bl; has = has | cand;
                     };
                     const int w_iters = (p.n_waste + 63) >> 6;
 #pragma unroll
