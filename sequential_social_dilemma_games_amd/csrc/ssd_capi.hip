@@ -19,7 +19,7 @@ using ssd::Params;
 static thread_local std::string g_create_error;
 
 struct ssd_env {
-    int game = 0, H = 0, W = 0, S = 0, E = 0, N = 0, view_len = 7, V = 15, beam_len = 5;
+    int game = 0, H = 0, W = 0, WP = 0, S = 0, E = 0, N = 0, view_len = 7, V = 15, beam_len = 5;
     int device = 0, keep_beams = 0, potential_waste = 0;
     uint64_t seed = 0;
     uint32_t env_base = 0;
@@ -60,7 +60,20 @@ void cleanup_probs(int potential, int n_h, double *p_apple, double *p_waste) {
     *p_apple = density <= restoration ? apple_p : (1 - (density - restoration) / (depletion - restoration)) * apple_p;
 }
 
-uint32_t magic(uint32_t d) { return d ? (uint32_t)(4294967296ull / d) + 1u : 0u; }
+constexpr uint8_t kVoid = '0';      // the glyph utility_funcs.py:94-114 pads views with; fills the row padding of the grids
+
+// dense [E][H][W] (the ABI's layout) <-> the engine's padded-row grids [E][S], row stride WP
+void pack_grid(const ssd_env *env, const int8_t *dense, std::vector<uint8_t> &grid, uint8_t pad) {
+    grid.assign((size_t)env->E * env->S, pad);
+    for (int e = 0; e < env->E; ++e)
+        for (int r = 0; r < env->H; ++r)
+            std::memcpy(grid.data() + (size_t)e * env->S + (size_t)r * env->WP, dense + ((size_t)e * env->H + r) * env->W, env->W);
+}
+void unpack_grid(const ssd_env *env, const std::vector<uint8_t> &grid, int8_t *dense) {
+    for (int e = 0; e < env->E; ++e)
+        for (int r = 0; r < env->H; ++r)
+            std::memcpy(dense + ((size_t)e * env->H + r) * env->W, grid.data() + (size_t)e * env->S + (size_t)r * env->WP, env->W);
+}
 
 template <typename T>
 int dev_alloc(ssd_env *env, T **out, size_t count, bool zero = true) {
@@ -190,18 +203,21 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
     env->view_len = cfg->view_len; env->V = V; env->beam_len = cfg->beam_len;
     env->device = cfg->device_id; env->keep_beams = cfg->keep_beams ? 1 : 0;
     env->seed = cfg->seed; env->env_base = cfg->env_index_base;
-    const int S = (hw + 15) & ~15;
-    env->S = S;
+    // grid layout (ssd_kernels.hip): row stride WP = W + view_len, padding = void glyph; LDS aprons of view_len rows
+    const int WP = W + cfg->view_len, S = (H * WP + 15) & ~15;
+    env->WP = WP; env->S = S;
 
     // static per-map tables (map_env.py:93-101, harvest.py:22-26, cleanup.py:44-62)
-    std::vector<uint8_t> reset_world(S, 0);
-    std::vector<uint16_t> spawn_cells, apple_cells, waste_cells;
+    std::vector<uint8_t> reset_world(S, kVoid);
+    std::vector<uint32_t> spawn_cells, apple_cells, waste_cells;   // grid index | dense index << 16
     const char apple_ch = cfg->game == SSD_GAME_HARVEST ? 'A' : 'B';
-    for (int c = 0; c < hw; ++c) {
-        const char b = cfg->base_map[c];
-        if (b == apple_ch) apple_cells.push_back((uint16_t)c);
-        if (cfg->game == SSD_GAME_CLEANUP && (b == 'H' || b == 'R')) { waste_cells.push_back((uint16_t)c); env->potential_waste++; }
-        if (b == 'P') spawn_cells.push_back((uint16_t)c);
+    for (int dc = 0; dc < hw; ++dc) {
+        const char b = cfg->base_map[dc];
+        const int c = (dc / W) * WP + dc % W;                   // grid index of the cell
+        const uint32_t entry = (uint32_t)c | ((uint32_t)dc << 16);
+        if (b == apple_ch) apple_cells.push_back(entry);
+        if (cfg->game == SSD_GAME_CLEANUP && (b == 'H' || b == 'R')) { waste_cells.push_back(entry); env->potential_waste++; }
+        if (b == 'P') spawn_cells.push_back(entry);
         char w = ' ';                         // reset_map (:560-564) + custom_reset (harvest.py:57-60, cleanup.py:84-92)
         if (b == '@') w = '@';
         else if (cfg->game == SSD_GAME_HARVEST && b == 'A') w = 'A';
@@ -233,10 +249,11 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
     }
 
     Params &p = env->p;
-    p.E = E; p.N = N; p.H = H; p.W = W; p.S = S;
+    p.E = E; p.N = N; p.H = H; p.W = W; p.WP = WP; p.S = S;
+    p.A0 = (cfg->view_len * (WP + 1) + 15) & ~15;
+    p.A1 = (cfg->view_len * WP + 15) & ~15;
     p.view_len = cfg->view_len; p.V = V; p.beam_len = cfg->beam_len;
     p.keep_beams = env->keep_beams;
-    p.w_magic = magic((uint32_t)W);
     p.v_magic16 = (65536u + (uint32_t)V - 1u) / (uint32_t)V;
     p.seed_lo = (uint32_t)cfg->seed; p.seed_hi = (uint32_t)(cfg->seed >> 32); p.env_base = cfg->env_index_base;
     p.n_spawn = (int)spawn_cells.size(); p.n_thr = n_thr;
@@ -255,13 +272,13 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
         return rc;
     };
     int rc;
-    if (ssd::lds_bytes(S, 1, true) > 64 * 1024) { env->err = "map too large for the 64 KiB LDS budget"; return bail(SSD_E_INVALID); }
+    if (ssd::lds_bytes(p, 1, true) > 64 * 1024) { env->err = "map too large for the 64 KiB LDS budget"; return bail(SSD_E_INVALID); }
     if ((rc = dev_alloc(env, &p.world, (size_t)E * S))) return bail(rc);
     if (env->keep_beams) { if ((rc = dev_alloc(env, &p.beam, (size_t)E * S))) return bail(rc); }
     if ((rc = dev_alloc(env, &p.agents, (size_t)E * N))) return bail(rc);
     if (N > 0) {   // before the first reset every agent sits on interior cell (1,1), facing UP: stepping an env that
                    // was never reset is then well defined and cannot index outside the grid
-        std::vector<uint32_t> ag((size_t)E * N, (uint32_t)(W + 1) | (2u << 16));
+        std::vector<uint32_t> ag((size_t)E * N, (uint32_t)(WP + 1) | (2u << 16));
         if (hipMemcpy(p.agents, ag.data(), ag.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { env->err = "hipMemcpy(agents)"; return bail(SSD_E_DEVICE); }
     }
     if ((rc = dev_alloc(env, &p.status, 1))) return bail(rc);
@@ -269,19 +286,20 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
         std::vector<uint4> hdr(E);
         for (int e = 0; e < E; ++e) hdr[e] = make_uint4(0, 0, 0xFFFFFFFFu, 0);
         if ((rc = upload(env, &p.hdr, hdr))) return bail(rc);
-        std::vector<uint8_t> w0((size_t)E * S, 0);   // world starts blank (map_env.py:85), pads stay 0
-        for (int e = 0; e < E; ++e) std::memset(w0.data() + (size_t)e * S, ' ', hw);
+        std::vector<uint8_t> w0((size_t)E * S, kVoid);   // world starts blank (map_env.py:85)
+        for (int e = 0; e < E; ++e)
+            for (int r = 0; r < H; ++r) std::memset(w0.data() + (size_t)e * S + (size_t)r * WP, ' ', W);
         if (hipMemcpy(p.world, w0.data(), w0.size(), hipMemcpyHostToDevice) != hipSuccess) { env->err = "hipMemcpy(world)"; return bail(SSD_E_DEVICE); }
     }
-    uint8_t *d8; uint16_t *d16; uint32_t *d32; uint64_t *d64;
+    uint8_t *d8; uint32_t *d32; uint64_t *d64;
     if ((rc = upload(env, &d8, reset_world))) return bail(rc);
     p.reset_world = d8;
-    if ((rc = upload(env, &d16, spawn_cells))) return bail(rc);
-    p.spawn_cells = d16;
-    if ((rc = upload(env, &d16, apple_cells))) return bail(rc);
-    p.apple_cells = d16;
-    if ((rc = upload(env, &d16, waste_cells))) return bail(rc);
-    p.waste_cells = d16;
+    if ((rc = upload(env, &d32, spawn_cells))) return bail(rc);
+    p.spawn_cells = d32;
+    if ((rc = upload(env, &d32, apple_cells))) return bail(rc);
+    p.apple_cells = d32;
+    if ((rc = upload(env, &d32, waste_cells))) return bail(rc);
+    p.waste_cells = d32;
     if ((rc = upload(env, &d32, lut))) return bail(rc);
     p.lut = d32;
     {   // float32 of the reference's float64 normalisation (map_env.py:199), one entry per byte value
@@ -338,17 +356,17 @@ int ssd_get_state(ssd_env *env, int8_t *world, int8_t *beam, int16_t *pos, uint8
     if (!env) return SSD_E_INVALID;
     SSD_HIP(env, hipSetDevice(env->device));
     SSD_HIP(env, hipDeviceSynchronize());
-    const int E = env->E, N = env->N, S = env->S, hw = env->H * env->W, W = env->W;
+    const int E = env->E, N = env->N, S = env->S, WP = env->WP;
     if (world || beam) {
         std::vector<uint8_t> buf((size_t)E * S);
         if (world) {
             SSD_HIP(env, hipMemcpy(buf.data(), env->p.world, buf.size(), hipMemcpyDeviceToHost));
-            for (int e = 0; e < E; ++e) std::memcpy(world + (size_t)e * hw, buf.data() + (size_t)e * S, hw);
+            unpack_grid(env, buf, world);
         }
         if (beam) {
             if (!env->keep_beams) { env->err = "beam overlay is only kept with keep_beams"; return SSD_E_INVALID; }
             SSD_HIP(env, hipMemcpy(buf.data(), env->p.beam, buf.size(), hipMemcpyDeviceToHost));
-            for (int e = 0; e < E; ++e) std::memcpy(beam + (size_t)e * hw, buf.data() + (size_t)e * S, hw);
+            unpack_grid(env, buf, beam);
         }
     }
     if (pos || orient) {
@@ -356,7 +374,7 @@ int ssd_get_state(ssd_env *env, int8_t *world, int8_t *beam, int16_t *pos, uint8
         if (!ag.empty()) SSD_HIP(env, hipMemcpy(ag.data(), env->p.agents, ag.size() * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < ag.size(); ++i) {
             const uint32_t cell = ag[i] & 0xFFFFu;
-            if (pos) { pos[2 * i] = (int16_t)(cell / W); pos[2 * i + 1] = (int16_t)(cell % W); }
+            if (pos) { pos[2 * i] = (int16_t)(cell / WP); pos[2 * i + 1] = (int16_t)(cell % WP); }
             if (orient) orient[i] = (uint8_t)((ag[i] >> 16) & 3u);
         }
     }
@@ -388,21 +406,26 @@ int ssd_set_state(ssd_env *env, const int8_t *world, const int8_t *beam, const i
     if (!env) return SSD_E_INVALID;
     SSD_HIP(env, hipSetDevice(env->device));
     SSD_HIP(env, hipDeviceSynchronize());
-    const int E = env->E, N = env->N, S = env->S, hw = env->H * env->W, W = env->W, H = env->H;
+    const int E = env->E, N = env->N, hw = env->H * env->W, W = env->W, H = env->H, WP = env->WP;
     if (world || beam) {
-        std::vector<uint8_t> buf((size_t)E * S, 0);
+        std::vector<uint8_t> buf;
         // glyphs index the 128-entry colour table on the device: cells must be 7-bit ASCII
         for (size_t i = 0; world && i < (size_t)E * hw; ++i)
             if (world[i] <= 0) { env->err = "world cells must be 7-bit ASCII (1..127)"; return SSD_E_INVALID; }
         for (size_t i = 0; beam && i < (size_t)E * hw; ++i)
             if (beam[i] < 0) { env->err = "beam cells must be 0 or 7-bit ASCII"; return SSD_E_INVALID; }
         if (world) {
-            for (int e = 0; e < E; ++e) std::memcpy(buf.data() + (size_t)e * S, world + (size_t)e * hw, hw);
+            // the wall border is what keeps agents and beams inside the grid (the kernel has no bounds tests)
+            for (int e = 0; e < E; ++e)
+                for (int r = 0; r < H; ++r)
+                    for (int c = 0; c < W; c += (r == 0 || r == H - 1 || c == W - 1) ? 1 : W - 1)
+                        if (world[((size_t)e * H + r) * W + c] != '@') { env->err = "the map border must stay '@'"; return SSD_E_INVALID; }
+            pack_grid(env, world, buf, kVoid);
             SSD_HIP(env, hipMemcpy(env->p.world, buf.data(), buf.size(), hipMemcpyHostToDevice));
         }
         if (beam) {
             if (!env->keep_beams) { env->err = "beam overlay is only kept with keep_beams"; return SSD_E_INVALID; }
-            for (int e = 0; e < E; ++e) std::memcpy(buf.data() + (size_t)e * S, beam + (size_t)e * hw, hw);
+            pack_grid(env, beam, buf, 0);
             SSD_HIP(env, hipMemcpy(env->p.beam, buf.data(), buf.size(), hipMemcpyHostToDevice));
         }
     }
@@ -415,7 +438,7 @@ int ssd_set_state(ssd_env *env, const int8_t *world, const int8_t *beam, const i
                 const int r = pos[2 * i], c = pos[2 * i + 1];
                 // agents live strictly inside the wall border; a position on the border could step out of the grid
                 if (r < 1 || r >= H - 1 || c < 1 || c >= W - 1) { env->err = "agent position must be inside the map's wall border"; return SSD_E_INVALID; }
-                cell = (uint32_t)(r * W + c);
+                cell = (uint32_t)(r * WP + c);
             }
             if (orient) { if (orient[i] > 3) { env->err = "orientation code must be 0..3"; return SSD_E_INVALID; } o = orient[i]; }
             ag[i] = cell | (o << 16);

@@ -7,7 +7,7 @@ namespace ssd {
 constexpr int kWave = 64;          // CDNA wavefront width
 constexpr int kMaxEnvsPerBlock = 16; // one wavefront per env; a workgroup holds 1..16 envs (chosen per launch, see launch())
 constexpr int kMaxAgents = 64;     // lanes = agents in the move / beam phases
-constexpr int kMaxCells = 4096;    // H*W, bounded by the u64 per-lane spawn bitmask and by LDS
+constexpr int kMaxCells = 4096;    // H*W, bounded by the u64 per-lane spawn bitmask and by LDS (grid indices stay below 2^16)
 constexpr int kMaxBeamLen = 21;    // 3 rays * beam_len lanes must fit one wavefront
 
 constexpr int kListRegs = 3;       // per-lane registers holding the first 192 entries of a static cell list
@@ -21,12 +21,14 @@ enum Stream : uint32_t {
 
 struct Params {
     // dimensions
-    int32_t E, N, H, W, S;         // S = H*W rounded up to 16 (per-env stride of the grids in HBM)
+    int32_t E, N, H, W;
+    int32_t WP, S;                 // grid layout: row stride WP = W + view_len (row padding = '0'), S = H*WP rounded up to 16
+                                   // (per-env stride of the grids in HBM); cell index = row * WP + col everywhere
+    int32_t A0, A1;                // LDS aprons of the world layer (bytes, multiples of 16): view_len rows of '0' above / below
     int32_t view_len, V, beam_len;
     int32_t mode, rotate, keep_beams, num_actions_random;
     int32_t obs_f32;               // obs is float32 [E,N,V,V,3] (SSD_OBS_F32) instead of uint8
     int32_t horizon;               // > 0: done = (t >= horizon), RLlib's `horizon` (train_baseline.py:131); 0: never done
-    uint32_t w_magic;              // floor(2^32 / W) + 1 : cell / W for cell < 2^16
     uint32_t v_magic16;            // ceil(2^16 / V): pp / V == (pp * v_magic16) >> 16 for pp < V*V, V <= 31
     uint32_t seed_lo, seed_hi, env_base;
     int32_t n_spawn, n_thr, n_apple, n_waste;
@@ -38,9 +40,10 @@ struct Params {
     uint32_t *status;              // [1]     SSD_ST_* bits
     // static tables in HBM (L2-resident)
     const uint8_t *reset_world;    // [S]     world right after reset_map()
-    const uint16_t *spawn_cells;   // [n_spawn] 'P' cells, row-major (map_env.py:96-99)
-    const uint16_t *apple_cells;   // [n_apple] 'A' (harvest.py:22-26) / 'B' (cleanup.py:53-54) cells, row-major
-    const uint16_t *waste_cells;   // [n_waste] 'H' or 'R' cells (cleanup.py:59-60), row-major
+    // cell list entries: grid index (row * WP + col) | dense index (row * W + col, the PRNG's cell key) << 16
+    const uint32_t *spawn_cells;   // [n_spawn] 'P' cells, row-major (map_env.py:96-99)
+    const uint32_t *apple_cells;   // [n_apple] 'A' (harvest.py:22-26) / 'B' (cleanup.py:53-54) cells, row-major
+    const uint32_t *waste_cells;   // [n_waste] 'H' or 'R' cells (cleanup.py:59-60), row-major
     const uint32_t *lut;           // [128]   r | g << 8 | b << 16
     const float *f32lut;           // [256]   float32((x - 128.0) / 255.0), exact (host-built)
     const uint64_t *thr_ca;        // [n_thr] Cleanup apple thresholds by #'H'
@@ -59,8 +62,8 @@ struct Params {
     unsigned long long *stamps;    // [E][16] s_memtime stamps; diagnostic builds (-DSSD_STAMPS) only, else null
 };
 
-size_t lds_bytes(int S, int envs_per_block, bool f32);
-int envs_per_block(int E, int S, bool f32);
+size_t lds_bytes(const Params &p, int envs_per_block, bool f32);
+int envs_per_block(const Params &p, bool f32);
 void launch(const Params &p, int game, void *stream);
 void launch_render_full(const Params &p, int e, uint8_t *rgb_dev, void *stream);
 

@@ -36,9 +36,6 @@ constexpr uint32_t kStBadAction = 1u << 0;
 constexpr uint32_t kStNoSpawn = 1u << 1;
 constexpr uint32_t kStMoveLookup = 1u << 2;
 
-constexpr int kObsBatch = 1;       // agents rendered per pass of the observation phase (1: each agent's store goes out as
-                                   // soon as it is ready, so the store drain overlaps the remaining agents; measured best)
-
 // ---------------------------------------------------------------------------------------------
 // shared PRNG (prng.py): triple32 chain
 // ---------------------------------------------------------------------------------------------
@@ -144,19 +141,30 @@ __device__ __forceinline__ uint32_t count_bytes_eq(uint32_t x, uint32_t ch) {
     do {                                                                                           \
         if (p.stamps && lane == 0 && e < p.E) p.stamps[(size_t)e * 16 + (i)] = __builtin_readcyclecounter(); \
     } while (0)
+#define SSD_STAMP_RT(i) /* 100 MHz constant clock, the same on every XCD */                       \
+    do {                                                                                           \
+        if (p.stamps && lane == 0 && e < p.E) p.stamps[(size_t)e * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #define SSD_SKIP(bit) ((p.dbg_skip >> (bit)) & 1u)
 #else
 #define SSD_STAMP(i)
+#define SSD_STAMP_RT(i)
 #define SSD_SKIP(bit) false
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// LDS layout of one workgroup: per wave (= per env)  lut[128] u32 | scratch[64] u16 |
-// f32lut[256] (float32-obs kernels only) | world[S] | beam[S] | occ[S]
+// LDS layout of one workgroup: per wave (= per env)  lut[128] u32 | scratch[64] u32 |
+// f32lut[256] (float32-obs kernels only) | apron[A0] | world[S] | apron[A1] | beam[S] | occ[S]
 // Waves never read each other's LDS, so the kernel has no workgroup barrier.
+//
+// Grid layout (HBM and LDS alike): row stride WP = W + view_len, the view_len bytes after each row hold the
+// void glyph '0'; in LDS the world layer additionally has view_len rows of '0' above and below (the aprons).
+// An agent's whole (2*view_len+1)^2 window -- the map cells AND the '0' padding that
+// utility_funcs.py:94-114 adds around the map -- is then plain memory around the agent's cell: the
+// observation phase needs no bounds test and no row / column arithmetic at all.
 // ---------------------------------------------------------------------------------------------
-__host__ size_t lds_bytes(int S, int envs_per_block, bool f32) {
-    return (size_t)envs_per_block * (128 * 4 + 128 + (f32 ? 256 * 4 : 0) + 3 * (size_t)S);
+__host__ size_t lds_bytes(const Params &p, int envs_per_block, bool f32) {
+    return (size_t)envs_per_block * (128 * 4 + 256 + (f32 ? 256 * 4 : 0) + (size_t)p.A0 + (size_t)p.A1 + 3 * (size_t)p.S);
 }
 
 // Envs (= waves) per workgroup.  Waves are independent, so this only changes dispatch granularity; measured on
@@ -164,7 +172,8 @@ __host__ size_t lds_bytes(int S, int envs_per_block, bool f32) {
 // E=8192: 21.9 / 22.0 / 21.7 / 22.8;  E=65536: 111 / 113 / 117 / 136.  So: big blocks while the whole batch is one
 // round with at most one block per CU (256 CUs), small blocks once CUs run several rounds, and never fewer than
 // 256 blocks when the batch is small.  SSD_ENVS_PER_BLOCK overrides (tuning).
-__host__ int envs_per_block(int E, int S, bool f32) {
+__host__ int envs_per_block(const Params &p, bool f32) {
+    const int E = p.E;
     static const int forced = [] { const char *v = getenv("SSD_ENVS_PER_BLOCK"); return v ? atoi(v) : 0; }();
     auto pow2floor = [](int x) { int p = 1; while (p * 2 <= x) p *= 2; return p; };
     int fill = pow2floor(E / 256 > 0 ? E / 256 : 1);            // keep >= 256 blocks
@@ -172,7 +181,7 @@ __host__ int envs_per_block(int E, int S, bool f32) {
     int epb = fill < rounds ? fill : rounds;
     if (epb > kMaxEnvsPerBlock) epb = kMaxEnvsPerBlock;
     if (forced >= 1 && forced <= kMaxEnvsPerBlock) epb = forced;
-    while (epb > 1 && lds_bytes(S, epb, f32) > 64 * 1024) epb /= 2;
+    while (epb > 1 && lds_bytes(p, epb, f32) > 64 * 1024) epb /= 2;
     return epb;
 }
 
@@ -189,25 +198,28 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
     // the wave index and everything derived from it (env index, LDS region, global offsets) is wave-uniform:
     // say so, and the per-env address arithmetic runs on the scalar unit instead of as 64-bit VALU multiplies
     const int wv = (int)rfl((uint32_t)tid >> 6);
-    const int W = FAST ? (GAME == 0 ? 38 : 18) : p.W, H = FAST ? (GAME == 0 ? 16 : 25) : p.H;
-    const int S = FAST ? (GAME == 0 ? 608 : 464) : p.S;
+    // FAST: the shipped maps with view_len 7 -- Harvest 16 x (38 + 7), Cleanup 25 x (18 + 7)
+    const int WP = FAST ? (GAME == 0 ? 45 : 25) : p.WP;
+    const int S = FAST ? (GAME == 0 ? 720 : 640) : p.S;
+    const int A0 = FAST ? (GAME == 0 ? 336 : 192) : p.A0, A1 = FAST ? (GAME == 0 ? 320 : 176) : p.A1;
     const int N = NA > 0 ? NA : p.N;
     const bool has_order = !FAST && p.order != nullptr, keep_beams = !FAST && p.keep_beams != 0;
-    uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + (size_t)wv * (512 + 128 + (F32 ? 1024 : 0) + 3 * (size_t)S));
-    uint16_t *s_tmp = reinterpret_cast<uint16_t *>(s_lut + 128);    // 64 cells of scratch (respawn compaction)
-    float *s_f32 = reinterpret_cast<float *>(s_lut + 160);          // float32-observation kernels only
-    uint8_t *s_world = reinterpret_cast<uint8_t *>(s_lut + 160 + (F32 ? 256 : 0));
-    uint8_t *s_beam = s_world + S;
+    uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + (size_t)wv * (512 + 256 + (F32 ? 1024 : 0) + (size_t)A0 + (size_t)A1 + 3 * (size_t)S));
+    uint32_t *s_tmp = s_lut + 128;                                  // 64 list entries of scratch (respawn compaction)
+    float *s_f32 = reinterpret_cast<float *>(s_lut + 192);          // float32-observation kernels only
+    uint8_t *s_world = reinterpret_cast<uint8_t *>(s_lut + 192 + (F32 ? 256 : 0)) + A0;
+    uint8_t *s_beam = s_world + S + A1;
     uint8_t *s_occ = s_beam + S;
 
     // Kernel arguments are fetched lazily by default, one scalar-cache round trip per basic block that
     // needs one.  Pin what the prologue needs into SGPRs here so that the loads go out as one batch.
     asm volatile("" ::"s"(p.hdr), "s"(p.agents), "s"(p.world), "s"(p.lut), "s"(p.apple_cells), "s"(p.obs),
-                 "s"(p.actions), "s"(p.order), "s"(p.n_apple), "s"(p.num_actions_random), "s"(p.w_magic));
+                 "s"(p.actions), "s"(p.order), "s"(p.n_apple), "s"(p.num_actions_random));
     const int e = blockIdx.x * (int)(blockDim.x >> 6) + wv;
     constexpr int mode = MODE;                               // compile-time: step / reset / observe
     bool active = e < p.E;                                   // wave-uniform
     if (active && mode == kModeReset && p.mask) active = p.mask[e] != 0;
+    SSD_STAMP_RT(10);
     SSD_STAMP(0);
 
     if (active) {
@@ -255,6 +267,12 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
             *reinterpret_cast<uint4 *>(s_beam + lane * 16) = b0;
             *reinterpret_cast<uint4 *>(s_occ + lane * 16) = make_uint4(0, 0, 0, 0);
         }
+        if (p.obs) {                                         // the aprons of the world layer: '0' (void) cells
+            const uint4 z = make_uint4(0x30303030u, 0x30303030u, 0x30303030u, 0x30303030u);
+            const int n0 = A0 >> 4, n1 = A1 >> 4;
+            for (int i = lane; i < n0 + n1; i += 64)
+                *reinterpret_cast<uint4 *>(i < n0 ? s_world - A0 + i * 16 : s_world + S + (i - n0) * 16) = z;
+        }
         for (int i = lane * 16 + 1024; i < S; i += 1024) {   // maps above 1024 cells
             uint4 bv = make_uint4(0, 0, 0, 0);
             if (mode == kModeObserve && keep_beams) bv = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + i);
@@ -277,15 +295,15 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 bool has = false;
                 uint32_t bh = 0, bl = 0;                     // lane-local min of (~draw, ~cell) = max of (draw, cell)
                 for (int s = lane; s < p.n_spawn; s += 64) {
-                    const uint32_t c = p.spawn_cells[s];
+                    const uint32_t ce = p.spawn_cells[s], c = ce & 0xFFFFu;         // grid index | dense index << 16
                     if (s_occ[c] == 0) {
-                        const uint32_t kh = ~draw(pk_pt, ((uint32_t)i << 16) | c), kl = ~c;
+                        const uint32_t kh = ~draw(pk_pt, ((uint32_t)i << 16) | (ce >> 16)), kl = ~c;
                         if (!has || kh < bh || (kh == bh && kl < bl)) { bh = kh; bl = kl; has = true; }
                     }
                 }
                 uint32_t oh, ol, chosen;
                 if (wave_argmin_pair(has, bh, bl, oh, ol)) chosen = ~ol;
-                else { status |= kStNoSpawn; chosen = p.n_spawn ? p.spawn_cells[0] : (uint32_t)(W + 1); }
+                else { status |= kStNoSpawn; chosen = p.n_spawn ? (p.spawn_cells[0] & 0xFFFFu) : (uint32_t)(WP + 1); }
                 if (lane == i) { cell = chosen; orient = randint(draw(pk_rot, (uint32_t)i), 4); }
                 s_occ[chosen] = agent_glyph((uint32_t)i);    // all lanes, same address, same value
                 wave_sync();
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 // rotate_action (:701-716): UP (v) LEFT (vc,-vr) RIGHT (-vc,vr) DOWN (-v)
                 const int dr = orient == 2 ? vr : orient == 0 ? vc : orient == 1 ? -vc : -vr;
                 const int dc = orient == 2 ? vc : orient == 0 ? -vr : orient == 1 ? vr : -vc;
-                const uint32_t cand = (uint32_t)((int)cell + dr * W + dc);
+                const uint32_t cand = (uint32_t)((int)cell + dr * WP + dc);
                 // agent.py:105-113 return_valid_pos (the agent's grid agrees with world_map on '@')
                 tcell = (mover & (s_world[cand] != '@')) ? cand : cell;
             }
@@ -465,22 +483,19 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 const bool fire = aa == kFire, clean = !fire;                       // harvest.py:62-67, cleanup.py:94-111
                 if (fire && lane == (int)a) rew -= 1;                               // agent.py:170-172 fire_beam('F')
                 // update_map_fire (map_env.py:566-649): lane = (ray q, step kk)
-                const uint32_t pc = rl(cell, a);
-                const int pr = (int)__umulhi(pc, p.w_magic), pcc = (int)pc - pr * W;
+                const int pc = (int)rl(cell, a);
                 int dr, dc;
                 unit_vec((int)rl(orient, a), dr, dc);
-                const int rr = -dc, rc = dr;                                        // rotate_right(d) (:607)
+                const int dlin = dr * WP + dc, rlin = -dc * WP + dr;                // d and rotate_right(d) = (-dc, dr) (:607) as cell offsets
                 const int q = (lane >= L) + (lane >= 2 * L), kk = lane - q * L;
                 const bool inray = lane < 3 * L;
-                const int sr = pr + (q == 1 ? rr - dr : q == 2 ? -rr - dr : 0);     // :608-609 start positions
-                const int sc = pcc + (q == 1 ? rc - dc : q == 2 ? -rc - dc : 0);
-                const int r2 = sr + dr * (kk + 1), c2 = sc + dc * (kk + 1);
-                const bool inb = inray & ((unsigned)r2 < (unsigned)H) & ((unsigned)c2 < (unsigned)W);   // :615 test_if_in_bounds
-                const int cidx = inb ? r2 * W + c2 : 0;
-                const uint8_t wraw = s_world[cidx], oraw = s_occ[cidx];            // unconditional loads (cell 0 when out of the map)
-                const uint8_t wch = inb ? wraw : (uint8_t)'@';
-                const uint8_t och = inb ? oraw : (uint8_t)0;
-                const bool pass = inb & (wch != '@');                               // :616
+                // :608-609 rays start at pos, pos + right - d, pos - right - d; ray cell kk is start + (kk + 1) * d.
+                // The map's border is wall (ssd_create / ssd_set_state insist) and a ray ends at the first '@'
+                // (:616), so the in-bounds test of :615 can never be what stops it: cells past the wall are
+                // read (harmlessly, possibly outside the grid) and ignored by the first-stop logic below.
+                const int cidx = inray ? pc + (q == 1 ? rlin : q == 2 ? -rlin : 0) + dlin * (kk + (q == 0)) : pc;
+                const uint8_t wch = s_world[cidx], och = s_occ[cidx];
+                const bool pass = inray & (wch != '@');                             // :616
                 const bool stopper = pass & ((och != 0) | (clean & (wch == 'H')));  // :621 agents absorb, :639 blocking cell
                 const uint64_t mf = ballot(inray & !pass), ms = ballot(stopper);
                 const uint32_t f = (uint32_t)(mf >> (q * L)) & rmask, s = (uint32_t)(ms >> (q * L)) & rmask;
@@ -512,13 +527,15 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
         SSD_STAMP(4);   // beams
         if (mode != kModeObserve) {
             // ---- custom_map_update (map_env.py:187 / :230): respawn ----
-            // Lanes walk the map's static apple-point list (row-major, as the reference iterates it).
+            // Lanes walk the map's static apple-point list (row-major, as the reference iterates it).  A list entry is
+            // grid index | dense index << 16: the grid index addresses the padded-row layers, the dense index
+            // (row * W + col, what prng.py keys the per-cell draws with) feeds the PRNG.
             // The LDS reads of one list entry are unconditional (padding entries point at an interior
             // cell), so they go out as one independent batch.
             uint64_t spawn_bits = 0;                                                // bit j: list entry lane + 64*j gets an apple
             const uint32_t pk_apple = phase_key(key, t, kApple);
             const int a_iters = (p.n_apple + 63) >> 6;
-            const uint32_t safe = (uint32_t)(W + 1);                                // cell (1,1)
+            const uint32_t safe = (uint32_t)(WP + 1);                               // cell (1,1)
             uint32_t waste_cell = 0xFFFFFFFFu;
             uint32_t waste_count = 0;                                               // #'H' the probabilities were computed from
             if (!SSD_SKIP(3)) {
@@ -531,16 +548,17 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 const uint32_t t0 = p.thr_h32[0], d1 = p.thr_h32[1] - t0, d2 = p.thr_h32[2] - p.thr_h32[1],
                                d3 = p.thr_h32[3] - p.thr_h32[2];
                 // 3x3 apple count, threshold and keyed draw of one candidate cell (:90-103)
-                auto wins = [&](uint32_t c) -> bool {
+                auto wins = [&](uint32_t ce) -> bool {
+                    const int c = (int)(ce & 0xFFFFu);
                     uint32_t n = 0;
 #pragma unroll
                     for (int dr = -1; dr <= 1; ++dr)
 #pragma unroll
                         for (int dc = -1; dc <= 1; ++dc)
-                            if (dr != 0 || dc != 0) n += s_world[(int)c + dr * W + dc] == 'A';
+                            if (dr != 0 || dc != 0) n += s_world[c + dr * WP + dc] == 'A';
                     const uint32_t thr = t0 + (n >= 1 ? d1 : 0u) + (n >= 2 ? d2 : 0u) + (n >= 3 ? d3 : 0u);   // SPAWN_PROB[min(n, 3)]
                     const bool always = ((p.thr_h_always >> (n < 3 ? n : 3u)) & 1u) != 0;
-                    return (draw(pk_apple, c) < thr) | always;
+                    return (draw(pk_apple, ce >> 16) < thr) | always;
                 };
                 // Pass 1 (cheap): which list entries are candidates at all -- an empty cell nobody stands on (:88).
                 bool el[kListRegs];
@@ -549,7 +567,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
 #pragma unroll
                 for (int j = 0; j < kListRegs; ++j) {
                     const bool valid = lane + 64 * j < p.n_apple;
-                    const uint32_t c = valid ? alist[j] : safe;
+                    const uint32_t c = (valid ? alist[j] : safe) & 0xFFFFu;
                     el[j] = valid & (s_world[c] != 'A') & (s_occ[c] == 0);
                     em[j] = ballot(el[j]);
                     total += __builtin_popcountll(em[j]);
@@ -563,15 +581,15 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                         for (int j = 0; j < kListRegs; ++j) {
                             const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(em[j] >> 32),
                                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)em[j], 0u));
-                            if (el[j]) s_tmp[slot] = (uint16_t)alist[j];
+                            if (el[j]) s_tmp[slot] = alist[j];
                             base += __builtin_popcountll(em[j]);
                         }
                         wave_sync();
                         const bool mine = lane < total;
-                        const uint32_t c = mine ? (uint32_t)s_tmp[lane] : safe;
+                        const uint32_t c = mine ? s_tmp[lane] : safe;
                         const bool hit = mine & wins(c);
                         wave_sync();                                                // every count used the pre-spawn map (:73)
-                        if (hit) s_world[c] = 'A';
+                        if (hit) s_world[c & 0xFFFFu] = 'A';
                     }
                 } else {
                     // general form: every lane evaluates its own list entries
@@ -584,7 +602,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                         const int idx = lane + 64 * j;
                         const bool valid = idx < p.n_apple;
                         const uint32_t c = valid ? p.apple_cells[idx] : safe;
-                        const bool cand = valid & (s_world[c] != 'A') & (s_occ[c] == 0);
+                        const bool cand = valid & (s_world[c & 0xFFFFu] != 'A') & (s_occ[c & 0xFFFFu] == 0);
                         spawn_bits |= (cand & wins(c)) ? bit(j) : 0ull;
                     }
                 }
@@ -602,8 +620,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 const uint64_t thr_a = p.thr_ca[nh], thr_w = p.thr_cw[nh];
                 auto apple = [&](int j, uint32_t c, bool valid) {                   // :135-141
                     c = valid ? c : safe;
-                    const uint8_t w = s_world[c], o = s_occ[c];
-                    const bool hit = valid & (w != 'A') & (o == 0) & ((uint64_t)draw(pk_apple, c) < thr_a);
+                    const uint8_t w = s_world[c & 0xFFFFu], o = s_occ[c & 0xFFFFu];
+                    const bool hit = valid & (w != 'A') & (o == 0) & ((uint64_t)draw(pk_apple, c >> 16) < thr_a);
                     spawn_bits |= hit ? bit(j) : 0ull;
                 };
 #pragma unroll
@@ -618,10 +636,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                     const uint32_t pk_coin = phase_key(key, t, kWasteCoin), pk_ord = phase_key(key, t, kWasteOrder);
                     bool has = false;
                     uint32_t bh = 0, bl = 0;
-                    auto waste = [&](uint32_t c, bool valid) {
-                        c = valid ? c : safe;
-                        const bool cand = valid & (s_world[c] != 'H') & ((uint64_t)draw(pk_coin, c) < thr_w);
-                        const uint32_t kh = draw(pk_ord, c);
+                    auto waste = [&](uint32_t ce, bool valid) {
+                        ce = valid ? ce : safe;
+                        const uint32_t c = ce & 0xFFFFu;                             // ties break on the cell: grid and dense order agree
+                        const bool cand = valid & (s_world[c] != 'H') & ((uint64_t)draw(pk_coin, ce >> 16) < thr_w);
+                        const uint32_t kh = draw(pk_ord, ce >> 16);
                         const bool better = cand & (!has | (kh < bh) | ((kh == bh) & (c < bl)));
                         bh = better ? kh : bh; bl = better ? c : bl; has = has | cand;
                     };
@@ -640,9 +659,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
             wave_sync();                                                            // counts use the pre-spawn map (harvest.py:73)
 #pragma unroll
             for (int j = 0; j < kListRegs; ++j)
-                if ((spawn_bits >> j) & 1) s_world[alist[j]] = 'A';
+                if ((spawn_bits >> j) & 1) s_world[alist[j] & 0xFFFFu] = 'A';
             for (int j = kListRegs; j < a_iters; ++j)
-                if ((spawn_bits >> j) & 1) s_world[p.apple_cells[lane + 64 * j]] = 'A';
+                if ((spawn_bits >> j) & 1) s_world[p.apple_cells[lane + 64 * j] & 0xFFFFu] = 'A';
             if (waste_cell != 0xFFFFFFFFu) s_world[waste_cell] = 'H';               // may land under an agent
             wave_sync();
 
@@ -684,34 +703,29 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
 
         // ---- per-agent observations (agent.py:76-78 -> utility_funcs.py:59-114 window with '0' padding,
         //      map_env.py:316-339 colour LUT, :669-689 rotate_view).  The wave renders its own env's agents
-        //      one after the other: lane = 4 consecutive cells of the V x V window (12 contiguous output
-        //      bytes), so the window coordinates are per-lane constants, the agent's position and rotation
+        //      one after the other: lane = 4 consecutive cells of the V x V view (12 contiguous output
+        //      bytes), so the view coordinates are per-lane constants, the agent's position and rotation
         //      are scalars, and one wave store covers up to 768 contiguous bytes of the uint8 obs tensor.
+        //      Thanks to the padded grid layout a view cell is ONE multiply-add away from its LDS address.
         //      An agent's block starts at a multiple of V*V*3 = 675 bytes, i.e. at any byte alignment:
         //      the 12-byte stores rely on gfx9's unaligned global access. ----
         if (p.obs) {
-            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            typedef __attribute__((address_space(3))) const uint8_t lds_u8;
             const int V = STD ? 15 : p.V, v = STD ? 7 : p.view_len, VV = V * V;
             uint8_t *out_env = p.obs + (size_t)e * N * VV * 3;
             // Per-agent constants, computed once with lane = agent and read back as scalars in the loop.
-            // Window cell (a, b) of an agent at (r0, c0) is grid cell (r0 - v + a, c0 - v + b); it is inside
-            // the map iff lo_a <= a <= lo_a + span_a and the same for b (packed 16-bit pairs below).
+            // Window cell (a, b) of an agent on grid cell `cell` is grid cell cell + (a - v) * WP + (b - v).
             // The view is rot90^k of the window (rotate_view, map_env.py:669-689; UP 0, LEFT 1, DOWN 2,
-            // RIGHT 3; reset observations are not rotated):  k=0 (a,b) = (i,j);  k=1 (j, V-1-i);
-            // k=2 (V-1-i, V-1-j) = (V-1,V-1) - [k=0];  k=3 (V-1-j, i) = (V-1,V-1) - [k=1].
-            uint32_t a_lo = 0, a_span = 0, a_s0 = 0, a_k = 0;
+            // RIGHT 3; reset observations are not rotated): view cell (i, j) shows window cell
+            //   k=0 (i, j)   k=1 (j, V-1-i)   k=2 (V-1-i, V-1-j)   k=3 (V-1-j, i)
+            // i.e. with lin0 = i*WP + j, lin1 = j*WP + (V-1-i) and C = (V-1)*(WP+1):
+            //   address = base + lin0 | base + lin1 | base + C - lin0 | base + C - lin1,   base = cell - v*(WP+1).
+            uint32_t a_s0 = 0, a_k = 0;
             if (is_agent) {
-                const int r0 = (int)__umulhi(cell, p.w_magic), c0 = (int)cell - r0 * W;
-                const int rb = r0 - v, cb = c0 - v;
-                const int lo_a = max(0, -rb), hi_a = min(V - 1, H - 1 - rb);
-                const int lo_b = max(0, -cb), hi_b = min(V - 1, W - 1 - cb);
-                a_lo = (uint32_t)lo_a | ((uint32_t)lo_b << 16);
-                a_span = (uint32_t)(hi_a - lo_a) | ((uint32_t)(hi_b - lo_b) << 16);
                 a_k = (mode == kModeStep || p.rotate) ? (orient == 2 ? 0u : orient == 0 ? 1u : orient == 3 ? 2u : 3u) : 0u;
-                // grid index of window cell (a,b) = rb*W + cb + a*W + b; for k >= 2 it is s0 - lin(k & 1)
-                a_s0 = (uint32_t)(rb * W + cb + (a_k >= 2 ? (V - 1) * W + (V - 1) : 0));
+                a_s0 = (uint32_t)((int)cell - v * (WP + 1) + (a_k >= 2 ? (V - 1) * (WP + 1) : 0));
             }
-            const uint32_t pkv = (uint32_t)(V - 1) * 0x00010001u;
+            const uint32_t world_lds = (uint32_t)(uintptr_t)(lds_u8 *)s_world;      // LDS byte address of grid cell 0
             for (int base = 0; base < VV; base += 256) {
                 // A lane renders 4 consecutive cells = one 12-byte store.  V*V is not a multiple of 4 (225 = 56*4 + 1):
                 // the lane holding the leftover cells starts 4 cells before the end instead, re-rendering up to 3
@@ -719,67 +733,44 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 // wave never takes a divergent byte-store path.  Views under 4 cells (view_len 0) use byte stores.
                 const int pp_raw = base + 4 * lane;
                 const bool lane_on = pp_raw < VV;
-                const int pp0 = (VV >= 4 && pp_raw > VV - 4) ? VV - 4 : pp_raw;
-                uint32_t P0[4], P1[4];
+                const int pp0 = (VV >= 4 && pp_raw > VV - 4) ? VV - 4 : pp_raw;     // lanes past the end repeat the last one
                 int L0[4], L1[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int pp = pp0 + q;
                     const int i = STD ? pp / 15 : (int)(((uint32_t)pp * p.v_magic16) >> 16), j = pp - i * V;   // pp / V, pp % V
-                    P0[q] = (uint32_t)i | ((uint32_t)j << 16);
-                    P1[q] = (uint32_t)j | ((uint32_t)(V - 1 - i) << 16);
-                    L0[q] = i * W + j;
-                    L1[q] = j * W + (V - 1 - i);
+                    L0[q] = i * WP + j;
+                    L1[q] = j * WP + (V - 1 - i);
                 }
                 const int ncell = lane_on ? VV - pp0 : 0;                           // >= 4 whenever VV >= 4
-                // kObsBatch agents per pass: all their grid reads go out together, then all LUT reads,
-                // then the stores (agents past N re-render agent N-1 and skip the store).
-                for (int ag0 = 0; ag0 < N; ag0 += kObsBatch) {
-                    uint32_t glyph[kObsBatch][4];
+                for (int ag = 0; ag < N; ++ag) {
+                    const uint32_t k = rl(a_k, ag);
+                    const uint32_t s0 = rl(a_s0, ag) + world_lds;
+                    const bool odd = (k & 1) != 0;
+                    const int sgn = k >= 2 ? -1 : 1;                                // one VGPR per agent: v_mad takes one scalar operand
+                    uint32_t px[4];
 #pragma unroll
-                    for (int u = 0; u < kObsBatch; ++u) {
-                        const int ag = min(ag0 + u, N - 1);
-                        const uint32_t lo = rl(a_lo, ag), span = rl(a_span, ag), k = rl(a_k, ag);
-                        const int s0 = (int)rl(a_s0, ag);
-                        const bool odd = (k & 1) != 0, neg = k >= 2;
-                        const int s1 = neg ? -1 : 1;
+                    for (int q = 0; q < 4; ++q) {
+                        const int x = odd ? L1[q] : L0[q];
+                        uint32_t addr;
+                        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr) : "v"(x), "v"(sgn), "s"(s0));
+                        // a cell outside the map reads the '0' of the row padding / aprons (utility_funcs.py:94-114)
+                        px[q] = s_lut[*(lds_u8 *)(uintptr_t)addr];
+                    }
+                    const size_t cell0 = (size_t)ag * VV + pp0;                     // first of this lane's cells within the env
+                    if (obs_f32) {
+                        // float32 mode: 3 floats per cell through the exact byte -> float table, 48 contiguous
+                        // bytes per lane (three 16-byte stores; an agent block starts at a multiple of 2700 B)
+                        float *dstf = reinterpret_cast<float *>(p.obs) + ((size_t)e * N * VV + cell0) * 3;
+                        float f[12];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const uint32_t x = odd ? P1[q] : P0[q];
-                            const u16x2 xv = __builtin_bit_cast(u16x2, x), kv = __builtin_bit_cast(u16x2, pkv);
-                            const u16x2 ab = neg ? (u16x2)(kv - xv) : xv;           // (a, b)
-                            const u16x2 t = ab - __builtin_bit_cast(u16x2, lo);
-                            const u16x2 m = __builtin_elementwise_min(t, __builtin_bit_cast(u16x2, span));
-                            const bool inb = __builtin_bit_cast(uint32_t, m) == __builtin_bit_cast(uint32_t, t);
-                            const int lin = __mul24(odd ? L1[q] : L0[q], s1) + s0;
-                            // an out-of-map lin may point anywhere (LDS reads are range-checked by the hardware and
-                            // the value is discarded): '0' padding, utility_funcs.py:94-114
-                            const uint32_t ch = s_world[lin];
-                            glyph[u][q] = inb ? ch : (uint32_t)'0';
+                            f[q * 3 + 0] = s_f32[px[q] & 0xFFu];
+                            f[q * 3 + 1] = s_f32[(px[q] >> 8) & 0xFFu];
+                            f[q * 3 + 2] = s_f32[(px[q] >> 16) & 0xFFu];
                         }
-                    }
-                    uint32_t px[kObsBatch][4];
-#pragma unroll
-                    for (int u = 0; u < kObsBatch; ++u)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) px[u][q] = s_lut[glyph[u][q]];
-#pragma unroll
-                    for (int u = 0; u < kObsBatch; ++u) {
-                        if (ag0 + u >= N) break;
-                        const size_t cell0 = (size_t)(ag0 + u) * VV + pp0;         // first of this lane's cells within the env
-                        if (obs_f32) {
-                            // float32 mode: 3 floats per cell through the exact byte -> float table, 48 contiguous
-                            // bytes per lane (three 16-byte stores; an agent block starts at a multiple of 2700 B)
-                            float *dstf = reinterpret_cast<float *>(p.obs) + ((size_t)e * N * VV + cell0) * 3;
-                            float f[12];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                f[q * 3 + 0] = s_f32[px[u][q] & 0xFFu];
-                                f[q * 3 + 1] = s_f32[(px[u][q] >> 8) & 0xFFu];
-                                f[q * 3 + 2] = s_f32[(px[u][q] >> 16) & 0xFFu];
-                            }
-                            if (VV >= 4) {
-                              if (lane_on) {
+                        if (VV >= 4) {
+                            if (lane_on) {
                                 typedef float f32x4 __attribute__((ext_vector_type(4)));
                                 struct __attribute__((packed, aligned(4))) F4 { f32x4 v; };
 #pragma unroll
@@ -787,52 +778,53 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                                     f32x4 v4 = {f[4 * k4], f[4 * k4 + 1], f[4 * k4 + 2], f[4 * k4 + 3]};
                                     reinterpret_cast<F4 *>(dstf + 4 * k4)->v = v4;
                                 }
-                              }
-                            } else {
-#pragma unroll
-                                for (int q = 0; q < 3; ++q)
-                                    if (q < ncell) { dstf[q * 3] = f[q * 3]; dstf[q * 3 + 1] = f[q * 3 + 1]; dstf[q * 3 + 2] = f[q * 3 + 2]; }
                             }
-                            continue;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 3; ++q)
+                                if (q < ncell) { dstf[q * 3] = f[q * 3]; dstf[q * 3 + 1] = f[q * 3 + 1]; dstf[q * 3 + 2] = f[q * 3 + 2]; }
                         }
-                        uint8_t *dst = out_env + cell0 * 3;
-                        if (VV >= 4) {
-                          if (lane_on) {
+                        continue;
+                    }
+                    uint8_t *dst = out_env + cell0 * 3;
+                    if (VV >= 4) {
+                        if (lane_on) {
                             typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
                             struct __attribute__((packed, aligned(1))) P3 { u32x3 v; };
                             u32x3 d;
                             // 4 x (r,g,b) -> 12 bytes with three byte permutes (v_perm_b32: selector bytes 0-3 pick from
                             // the second operand, 4-7 from the first)
-                            d.x = __builtin_amdgcn_perm(px[u][1], px[u][0], 0x04020100u);   // r0 g0 b0 r1
-                            d.y = __builtin_amdgcn_perm(px[u][2], px[u][1], 0x05040201u);   // g1 b1 r2 g2
-                            d.z = __builtin_amdgcn_perm(px[u][3], px[u][2], 0x06050402u);   // b2 r3 g3 b3
+                            d.x = __builtin_amdgcn_perm(px[1], px[0], 0x04020100u);   // r0 g0 b0 r1
+                            d.y = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);   // g1 b1 r2 g2
+                            d.z = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);   // b2 r3 g3 b3
                             reinterpret_cast<P3 *>(dst)->v = d;
-                          }
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 3; ++q)
-                                if (q < ncell) {
-                                    dst[q * 3 + 0] = (uint8_t)px[u][q];
-                                    dst[q * 3 + 1] = (uint8_t)(px[u][q] >> 8);
-                                    dst[q * 3 + 2] = (uint8_t)(px[u][q] >> 16);
-                                }
                         }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            if (q < ncell) {
+                                dst[q * 3 + 0] = (uint8_t)px[q];
+                                dst[q * 3 + 1] = (uint8_t)(px[q] >> 8);
+                                dst[q * 3 + 2] = (uint8_t)(px[q] >> 16);
+                            }
                     }
                 }
             }
         }
     }
     SSD_STAMP(9);       // observations issued
+    SSD_STAMP_RT(11);
 }
 
 // MapEnv.map_to_colors() on the whole grid of one env (map_env.py:316-339), one thread per cell.
 __global__ void ssd_render_full_kernel(const Params p, int e, uint8_t *rgb) {
     const int hw = p.H * p.W;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < hw; c += gridDim.x * blockDim.x) {
-        uint32_t ch = p.world[(size_t)e * p.S + c];
+        const int g = (c / p.W) * p.WP + c % p.W;                                    // dense cell -> padded-row grid index
+        uint32_t ch = p.world[(size_t)e * p.S + g];
         for (int i = 0; i < p.N; ++i)                                                // agents, index order (:289-297)
-            if ((p.agents[(size_t)e * p.N + i] & 0xFFFFu) == (uint32_t)c) ch = agent_glyph((uint32_t)i);
-        if (p.keep_beams) { const uint32_t b = p.beam[(size_t)e * p.S + c]; if (b) ch = b; }   // :299-300
+            if ((p.agents[(size_t)e * p.N + i] & 0xFFFFu) == (uint32_t)g) ch = agent_glyph((uint32_t)i);
+        if (p.keep_beams) { const uint32_t b = p.beam[(size_t)e * p.S + g]; if (b) ch = b; }   // :299-300
         const uint32_t px = p.lut[ch & 127u];
         rgb[c * 3 + 0] = (uint8_t)px; rgb[c * 3 + 1] = (uint8_t)(px >> 8); rgb[c * 3 + 2] = (uint8_t)(px >> 16);
     }
@@ -850,7 +842,8 @@ static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipS
         // among those the FAST ones for the game's shipped map called in the plain way
         const bool std_view = p.view_len == 7 && p.beam_len == 5;
         const bool fast = std_view && !p.order && !p.keep_beams &&
-                          (GAME == 0 ? (p.H == 16 && p.W == 38 && p.S == 608) : (p.H == 25 && p.W == 18 && p.S == 464));
+                          (GAME == 0 ? (p.H == 16 && p.W == 38 && p.WP == 45 && p.S == 720 && p.A0 == 336 && p.A1 == 320)
+                                     : (p.H == 25 && p.W == 18 && p.WP == 25 && p.S == 640 && p.A0 == 192 && p.A1 == 176));
         if (std_view && p.N == 5) {
             if (fast) launch_step<GAME, F32, 5, true, true>(p, grid, block, lds, s);
             else launch_step<GAME, F32, 5, true, false>(p, grid, block, lds, s);
@@ -868,9 +861,9 @@ static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipS
 
 void launch(const Params &p, int game, void *stream) {
     const bool f32 = p.obs && p.obs_f32;            // the float32-observation variant is a separate instantiation
-    const int epb = envs_per_block(p.E, p.S, f32);
+    const int epb = envs_per_block(p, f32);
     const dim3 grid((p.E + epb - 1) / epb), block(64 * epb);
-    const size_t lds = lds_bytes(p.S, epb, f32);
+    const size_t lds = lds_bytes(p, epb, f32);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (game == 0) { if (f32) launch_game<0, true>(p, grid, block, lds, s); else launch_game<0, false>(p, grid, block, lds, s); }
     else { if (f32) launch_game<1, true>(p, grid, block, lds, s); else launch_game<1, false>(p, grid, block, lds, s); }

@@ -34,6 +34,8 @@ def main():
     L.ssd_debug_set_stamps(eng._h, C.c_void_p(stamps.data_ptr()))
     acc = torch.zeros(9, dtype=torch.float64)
     span = 0.0
+    sq = torch.zeros(5, dtype=torch.float64)
+    eq = torch.zeros(5, dtype=torch.float64)
     reps = 50
     for _ in range(reps):
         eng.step_random(out=out)
@@ -41,14 +43,29 @@ def main():
         s = stamps.cpu().double()
         d = s[:, 1:10] - s[:, 0:9]
         acc += d.mean(dim=0)
-        span += float((s[:, 9].max() - s[:, 0].min()))
+        t0 = s[:, 10].min()                        # s_memrealtime: 100 MHz, common to all XCDs
+        span += float(s[:, 11].max() - t0) * 0.01
+        starts = (s[:, 10] - t0) * 0.01
+        ends = (s[:, 11] - t0) * 0.01
+        q = torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=torch.float64)
+        sq += torch.quantile(starts, q)
+        eq += torch.quantile(ends, q)
     acc /= reps
     tot = float(acc.sum())
     print("phase shares per wave (cycles of s_memtime; E=%d, %s)" % (E, "cleanup" if game else "harvest"))
     for n, v in zip(NAMES, acc.tolist()):
         print("  %-14s %9.0f  %5.1f %%" % (n, v, 100.0 * v / tot))
     print("  %-14s %9.0f" % ("sum", tot))
-    print("  first stamp -> last stamp over the grid: %.0f ticks" % (span / reps))
+    print("  first stamp -> last stamp over the grid: %.2f us" % (span / reps))
+    epb = int(os.environ.get("SSD_ENVS_PER_BLOCK", "0")) or None
+    if epb:                                        # blocks go round-robin to the 8 XCDs
+        xcd = (torch.arange(E) // epb) % 8
+        for x in range(8):
+            m = xcd == x
+            print("  XCD %d: starts %.2f..%.2f us, ends %.2f..%.2f us (last launch)" % (
+                x, float(starts[m].min()), float(starts[m].max()), float(ends[m].min()), float(ends[m].max())))
+    print("  wave start times us (min / 10 %% / median / 90 %% / max): " + " / ".join("%.2f" % v for v in (sq / reps).tolist()))
+    print("  wave end times   us (min / 10 %% / median / 90 %% / max): " + " / ".join("%.2f" % v for v in (eq / reps).tolist()))
 
 
 if __name__ == "__main__":
