@@ -145,8 +145,13 @@ __device__ __forceinline__ uint32_t count_bytes_eq(uint32_t x, uint32_t ch) {
     do {                                                                                           \
         if (p.stamps && lane == 0 && e < p.E) p.stamps[(size_t)e * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+#define SSD_NOTE(i, v)                                                                             \
+    do {                                                                                           \
+        if (p.stamps && lane == 0 && e < p.E) p.stamps[(size_t)e * 16 + (i)] = (unsigned long long)(v); \
+    } while (0)
 #define SSD_SKIP(bit) ((p.dbg_skip >> (bit)) & 1u)
 #else
+#define SSD_NOTE(i, v)
 #define SSD_STAMP(i)
 #define SSD_STAMP_RT(i)
 #define SSD_SKIP(bit) false
@@ -339,17 +344,37 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 if (!((acting >> lane) & 1)) act = -1;       // agents absent from the action dict do nothing
             }
 
+            // A launch lasts as long as its slowest wave.  How long a wave will take is known here: in Cleanup every
+            // beam costs ~0.5 us (they are traced one after the other), the conflict path of the moves ~1.5 us.  Waves
+            // with more work ahead issue ahead of the waves they share a SIMD with (which have slack); measured
+            // -0.5 us per 4096-env launch.  (Harvest traces all beams at once: no priority needed for them.)
+            if (GAME == 1) {
+                constexpr int kFireAct = 7, kCleanAct = 8;
+                const int ns = __builtin_popcountll(ballot(is_agent && (act == kFireAct || act == kCleanAct)));
+                if (ns >= 2) __builtin_amdgcn_s_setprio(2);
+                else if (ns == 1) __builtin_amdgcn_s_setprio(1);
+            }
             // ---- update_moves (map_env.py:357-543) ----
             const bool mover = !SSD_SKIP(0) && is_agent && act >= 0 && act <= 4;              // :383
             if (is_agent && (act == 5 || act == 6)) orient = turn(act, orient);   // :390-392
             uint32_t tcell = cell;
-            {   // every lane runs this (non-movers get a zero step), so the wall read is one unconditional LDS load
-                int vr, vc;
-                unit_vec(mover ? act : 4, vr, vc);
-                // rotate_action (:701-716): UP (v) LEFT (vc,-vr) RIGHT (-vc,vr) DOWN (-v)
-                const int dr = orient == 2 ? vr : orient == 0 ? vc : orient == 1 ? -vc : -vr;
-                const int dc = orient == 2 ? vc : orient == 0 ? -vr : orient == 1 ? vr : -vc;
-                const uint32_t cand = (uint32_t)((int)cell + dr * WP + dc);
+            {   // every lane runs this (non-movers get a zero step), so the wall read is one unconditional LDS load.
+                // MOVE_* vectors (map_env.py:11-15) and rotate_action (:701-716: UP v, LEFT (vc,-vr), RIGHT (-vc,vr),
+                // DOWN -v) as arithmetic on a cyclic direction index (0 (-1,0), 1 (0,1), 2 (1,0), 3 (0,-1)): the
+                // move code picks an index, the orientation adds a quarter-turn count.  Tables are 5-bit fields
+                // holding 8 * index, so the sum (mod 32, which the bit-field extract applies by itself) is the
+                // bit offset of the result's byte.
+                constexpr uint32_t kMoveIdx8 = (0u << 0) | (16u << 5) | (24u << 10) | (8u << 15);   // MOVE_* codes 0..3
+                constexpr uint32_t kTurns8 = (8u << 0) | (24u << 5) | (0u << 10) | (16u << 15);     // LEFT, RIGHT, UP, DOWN
+                const uint32_t sum = __builtin_amdgcn_ubfe(kMoveIdx8, (uint32_t)act * 5u, 5u) + __builtin_amdgcn_ubfe(kTurns8, orient * 5u, 5u);
+                int step;
+                if (FAST) {                                  // row stride fits a signed byte: the table holds the cell offsets
+                    const uint32_t off4 = ((uint32_t)(-WP) & 0xFFu) | (1u << 8) | ((uint32_t)WP << 16) | (0xFFu << 24);
+                    step = __builtin_amdgcn_sbfe(off4, sum, 8u);
+                } else {
+                    step = __builtin_amdgcn_sbfe(0x000100FFu, sum, 8u) * WP + __builtin_amdgcn_sbfe(0xFF000100u, sum, 8u);
+                }
+                const uint32_t cand = (uint32_t)((int)cell + ((mover & (act < 4)) ? step : 0));    // STAY (4) is a zero step
                 // agent.py:105-113 return_valid_pos (the agent's grid agrees with world_map on '@')
                 tcell = (mover & (s_world[cand] != '@')) ? cand : cell;
             }
@@ -360,15 +385,18 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
             // whatever the shuffle says (STAY / wall-blocked movers target their own cell and stay), and
             // since draws are counter-keyed there is no RNG state to advance.  Otherwise run the
             // reference algorithm in full.
-            bool clash = false;
+            uint64_t clashm = 0;                             // lanes whose target is agent j's cell or mover j's target, j != lane
             for (int j = 0; j < N; ++j) {
                 const uint32_t cj = rl(cell, j), tj = rl(tcell, j);
-                clash |= mover & (j != lane) & ((tcell == cj) | ((((M >> j) & 1) != 0) & (tcell == tj)));
+                const uint64_t on_cell = ballot(tcell == cj), on_target = ballot(tcell == tj);
+                clashm |= (on_cell | (((M >> j) & 1) ? on_target : 0ull)) & ~bit(j);
             }
-            const bool slow = ballot(clash) != 0;
+            const bool slow = (clashm & M) != 0;
+            SSD_NOTE(12, slow ? 1 : 0);
             if (!slow) {
                 if (mover) cell = tcell;
             } else {                                         // :415 (M != 0 here)
+                __builtin_amdgcn_s_setprio(3);               // the slowest waves of a launch come through here (1-2 % of the envs)
                 const int nm = __builtin_popcountll(M);
                 uint32_t perm = 0;                           // lane k: k-th entry of the (shuffled) zipped list
                 {
@@ -452,19 +480,23 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
         }
 
         SSD_STAMP(2);   // moves resolved
+        uint64_t highest = 0;                                // agents that are the highest index on their cell (agent_by_pos, :603)
         if (mode != kModeReset && !SSD_SKIP(1)) {
             // ---- consume (map_env.py:178-181, agent.py:177-183) + occupancy layer ----
             // Index order means: of several agents on one cell the LOWEST index eats the apple, and
             // agent_by_pos / the overlay show the HIGHEST index (:289-297, :603).
-            bool lower = false, higher = false;
+            // Wave masks on the scalar unit: agent j is the lowest (highest) index on its cell iff no lower (higher)
+            // bit is set among the agents standing where it stands.
+            const uint64_t agents = N >= 64 ? ~0ull : bit((uint32_t)N) - 1;
+            uint64_t lowest = 0;
             for (int j = 0; j < N; ++j) {
-                const bool same = is_agent & (rl(cell, j) == cell);     // bitwise on purpose: no short-circuit branches
-                lower |= same & (j < lane);
-                higher |= same & (j > lane);
+                const uint64_t here = ballot(cell == rl(cell, j)) & agents;
+                lowest |= (here & (bit(j) - 1)) ? 0ull : bit(j);
+                highest |= ((here >> j) >> 1) ? 0ull : bit(j);
             }
-            const bool eats = (mode == kModeStep) & is_agent & !lower & (s_world[cell] == 'A');
+            const bool eats = (mode == kModeStep) & __builtin_amdgcn_inverse_ballot_w64(lowest) & (s_world[cell] == 'A');
             if (eats) { s_world[cell] = ' '; rew += 1; }
-            if (is_agent && !higher) s_occ[cell] = agent_glyph((uint32_t)lane);
+            if (__builtin_amdgcn_inverse_ballot_w64(highest)) s_occ[cell] = agent_glyph((uint32_t)lane);
             wave_sync();
         }
 
@@ -475,7 +507,60 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
             const uint32_t rmask = (1u << L) - 1u;
             constexpr int kFire = 7, kClean = 8;
             uint64_t shooters = SSD_SKIP(2) ? 0ull : ballot(is_agent && (act == kFire || (GAME == 1 && act == kClean)));
-            for (int k = 0; shooters && k < nord; ++k) {
+            SSD_NOTE(13, __builtin_popcountll(shooters));
+            if (GAME == 0 && shooters) {
+                // Harvest: a FIRE beam changes nothing another beam reads (no cell types, no blocking cells, harvest.py:62-67;
+                // 'F' marks and penalties commute), so the rays of up to 64 / 3L shooters are traced in ONE pass:
+                // lane = (shooter slot g, ray q, step kk).  A wave with three shooters costs what one shooter costs.
+                const int R = 3 * L, G = STD ? 4 : 64 / R;
+                const int g = STD ? lane / 15 : lane / R, r = lane - g * R;
+                const int q = (r >= L) + (r >= 2 * L), kk = r - q * L;
+                const int cq = q == 1 ? 1 : q == 2 ? -1 : 0, ck = kk + (q == 0);   // ray cell = pos + cq * right + ck * d (:608-609)
+                const int sh = g * R + q * L;                                       // first lane of this lane's ray
+                if (is_agent && act == kFire) rew -= 1;                             // agent.py:170-172 fire_beam('F')
+                const uint32_t packed_agent = cell | (orient << 16);
+                while (shooters) {
+                    int a = -1, taken = 0;                                          // slot g <- the g-th remaining shooter
+                    for (; taken < G && shooters; ++taken) {
+                        const int b = __builtin_ctzll(shooters);
+                        a = (g == taken) ? b : a;
+                        shooters &= shooters - 1;
+                    }
+                    const bool inray = a >= 0;
+                    const uint32_t ar = (uint32_t)__builtin_amdgcn_ds_bpermute((inray ? a : 0) << 2, (int)packed_agent);
+                    const int pc = (int)(ar & 0xFFFFu);
+                    const uint32_t o8 = (ar >> 16) << 3;                            // orientation code * 8: LEFT RIGHT UP DOWN
+                    int dlin, rlin;                                                 // d and rotate_right(d) = (-dc, dr) (:607) as cell offsets
+                    if (FAST) {
+                        const uint32_t b = (uint32_t)WP & 0xFFu, nb = (uint32_t)(-WP) & 0xFFu;
+                        dlin = __builtin_amdgcn_sbfe(nb | (b << 8) | (0xFFu << 16) | (1u << 24), o8, 8u);   // -WP, WP, -1, 1
+                        rlin = __builtin_amdgcn_sbfe(0xFFu | (1u << 8) | (b << 16) | (nb << 24), o8, 8u);   // -1, 1, WP, -WP
+                    } else {
+                        const int dr = __builtin_amdgcn_sbfe(0x000001FFu, o8, 8u), dc = __builtin_amdgcn_sbfe(0x01FF0000u, o8, 8u);
+                        dlin = dr * WP + dc; rlin = -dc * WP + dr;
+                    }
+                    // The map's border is wall and a ray ends at the first '@' (:616), so the in-bounds test of :615 can
+                    // never be what stops it: cells past the wall are read (harmlessly) and ignored by the first-stop logic.
+                    const int cidx = inray ? pc + __mul24(rlin, cq) + __mul24(dlin, ck) : WP + 1;
+                    const uint8_t wch = s_world[cidx], och = s_occ[cidx];
+                    const bool pass = inray & (wch != '@');                         // :616
+                    const bool stopper = pass & (och != 0);                         // :621 agents absorb the beam
+                    const uint64_t mf = ballot(inray & !pass), ms = ballot(stopper);
+                    const uint32_t f = (uint32_t)(mf >> sh) & rmask, st = (uint32_t)(ms >> sh) & rmask;
+                    const int ff = f ? __builtin_ctz(f) : L, fs = st ? __builtin_ctz(st) : L;
+                    const int len = fs < ff ? fs + 1 : ff;                          // beam covers the stopping cell
+                    if (inray && kk < len) s_beam[cidx] = 'F';                      // :624 firing_points (nothing reads the beam layer here)
+                    // agent.py:166-168 hit('F'): the last-index agent (:603) on a cell where a ray stopped loses 50 per ray
+                    uint64_t hits = ballot(stopper & (kk == fs) & (fs < ff));
+                    const bool top = __builtin_amdgcn_inverse_ballot_w64(highest);
+                    for (; hits; hits &= hits - 1) {
+                        const uint32_t hit_cell = rl((uint32_t)cidx, (uint32_t)__builtin_ctzll(hits));
+                        rew -= (top & (cell == hit_cell)) ? 50 : 0;
+                    }
+                }
+                wave_sync();
+            }
+            for (int k = 0; GAME == 1 && shooters && k < nord; ++k) {
                 const uint32_t a = rl(ordv, k);
                 if (!((shooters >> a) & 1)) continue;
                 shooters &= ~bit(a);
@@ -739,24 +824,30 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 for (int q = 0; q < 4; ++q) {
                     const int pp = pp0 + q;
                     const int i = STD ? pp / 15 : (int)(((uint32_t)pp * p.v_magic16) >> 16), j = pp - i * V;   // pp / V, pp % V
-                    L0[q] = i * WP + j;
-                    L1[q] = j * WP + (V - 1 - i);
+                    // 24-bit multiply-adds (full rate; a plain `*` becomes a quarter-rate 32-bit multiply here)
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(L0[q]) : "v"(i), "s"(WP), "v"(j));
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(L1[q]) : "v"(j), "s"(WP), "v"(V - 1 - i));
                 }
+                uint32_t off3 = (uint32_t)pp0 * 3u;                                 // byte offset of the lane's cells in an agent's block
+                asm volatile("" : "+v"(off3));                                      // keep it in a register (else re-derived per agent)
                 const int ncell = lane_on ? VV - pp0 : 0;                           // >= 4 whenever VV >= 4
                 for (int ag = 0; ag < N; ++ag) {
                     const uint32_t k = rl(a_k, ag);
                     const uint32_t s0 = rl(a_s0, ag) + world_lds;
-                    const bool odd = (k & 1) != 0;
                     const int sgn = k >= 2 ? -1 : 1;                                // one VGPR per agent: v_mad takes one scalar operand
-                    uint32_t px[4];
+                    uint32_t addr[4], px[4];
+                    // wave-uniform branch on the rotation's parity instead of a per-cell select (the asm is volatile so
+                    // that the two arms are not merged back into selects)
+                    if (k & 1) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int x = odd ? L1[q] : L0[q];
-                        uint32_t addr;
-                        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr) : "v"(x), "v"(sgn), "s"(s0));
-                        // a cell outside the map reads the '0' of the row padding / aprons (utility_funcs.py:94-114)
-                        px[q] = s_lut[*(lds_u8 *)(uintptr_t)addr];
+                        for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[q]) : "v"(L1[q]), "v"(sgn), "s"(s0));
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[q]) : "v"(L0[q]), "v"(sgn), "s"(s0));
                     }
+                    // a cell outside the map reads the '0' of the row padding / aprons (utility_funcs.py:94-114)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) px[q] = s_lut[*(lds_u8 *)(uintptr_t)addr[q]];
                     const size_t cell0 = (size_t)ag * VV + pp0;                     // first of this lane's cells within the env
                     if (obs_f32) {
                         // float32 mode: 3 floats per cell through the exact byte -> float table, 48 contiguous
@@ -786,7 +877,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                         }
                         continue;
                     }
-                    uint8_t *dst = out_env + cell0 * 3;
+                    uint8_t *dst = out_env + (size_t)ag * VV * 3 + off3;
                     if (VV >= 4) {
                         if (lane_on) {
                             typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));

@@ -37,8 +37,10 @@ def main():
     sq = torch.zeros(5, dtype=torch.float64)
     eq = torch.zeros(5, dtype=torch.float64)
     reps = 50
+    burst = int(os.environ.get("SSD_PROFILE_BURST", "20"))     # launches back to back; the stamps are the last one's
     for _ in range(reps):
-        eng.step_random(out=out)
+        for _ in range(burst):
+            eng.step_random(out=out)
         torch.cuda.synchronize()
         s = stamps.cpu().double()
         d = s[:, 1:10] - s[:, 0:9]
@@ -51,6 +53,25 @@ def main():
         sq += torch.quantile(starts, q)
         eq += torch.quantile(ends, q)
     acc /= reps
+    # the last launch: wave duration by what the env had to do (notes written by the diagnostic build)
+    dur = (s[:, 11] - s[:, 10]) * 0.01
+    cyc = s[:, 9] - s[:, 0]
+    slow, shots = s[:, 12] > 0, s[:, 13]
+    print("  last launch, wave duration (us, 100 MHz clock) / cycles by work:")
+    for name, m in (("fast move, 0 shooters", (~slow) & (shots == 0)), ("fast move, 1 shooter", (~slow) & (shots == 1)),
+                    ("fast move, 2+ shooters", (~slow) & (shots >= 2)), ("slow move, 0 shooters", slow & (shots == 0)),
+                    ("slow move, 1+ shooters", slow & (shots >= 1))):
+        if m.any():
+            print("    %-24s %5.1f %% of envs: mean %.2f us, max %.2f us, mean %.0f cycles" % (
+                name, 100.0 * float(m.double().mean()), float(dur[m].mean()), float(dur[m].max()), float(cyc[m].mean())))
+    d_last = s[:, 1:10] - s[:, 0:9]
+    idx = dur.sort().indices
+    for name, sel in (("fastest 10 %", idx[: E // 10]), ("middle 10 %", idx[E // 2 - E // 20: E // 2 + E // 20]), ("slowest 1 %", idx[-max(E // 100, 1):])):
+        print("    %-13s phases (cycles): " % name + " ".join("%s %.0f" % (n.split()[0], v) for n, v in zip(NAMES, d_last[sel].mean(dim=0).tolist()) if n != "wg barrier")
+              + " | starts %.2f us" % float(starts[sel].mean()))
+    # position of the wave among the waves of its SIMD: envs e, e+? share a SIMD -- unknown mapping; report by end rank instead
+    order = dur.sort().values
+    print("    duration percentiles (us): " + " / ".join("%.2f" % float(order[int(q * (E - 1))]) for q in (0, 0.1, 0.5, 0.9, 0.99, 1.0)))
     tot = float(acc.sum())
     print("phase shares per wave (cycles of s_memtime; E=%d, %s)" % (E, "cleanup" if game else "harvest"))
     for n, v in zip(NAMES, acc.tolist()):
