@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--agents", type=int, default=None)
     ap.add_argument("--gather", action="store_true", help="RCCL all-gather of obs/rew after every step")
     ap.add_argument("--obs-f32", action="store_true", help="separate mode: the kernel writes float32 observations (4x the obs bytes)")
+    ap.add_argument("--per-step-calls", action="store_true", help="one Python call per step instead of ssd_rollout_random")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -111,8 +112,21 @@ def main():
             parallel.all_gather_batch(dist, out[0], world * E, world, out=gbuf[0])
             parallel.all_gather_batch(dist, out[1], world * E, world, out=gbuf[1])
 
-    for k in range(args.warmup):
-        one_step(k)
+    # Without --gather / --per-step-calls the steps are enqueued by ssd_rollout_random: the same launches (one step
+    # kernel per step into the same output buffers, a full reset every HORIZON steps), issued by one library call per
+    # chunk instead of one Python call per step, so that the host never starves the 9 us kernels.
+    ring = tuple(t.unsqueeze(0) for t in out)
+    use_rollout = not (do_gather or args.per_step_calls)
+
+    def run_steps(k0, n):
+        if use_rollout:
+            for c0 in range(k0, k0 + n, 1000):
+                eng.rollout_random(min(1000, k0 + n - c0), ring[0], ring[1], ring[2], reset_every=HORIZON, step0=c0)
+        else:
+            for k in range(k0, k0 + n):
+                one_step(k)
+
+    run_steps(0, args.warmup)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -120,9 +134,9 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()                                   # torch's current stream == the stream the kernels are launched on
-    for k in range(args.steps):
-        one_step(args.warmup + k)
+    run_steps(args.warmup, args.steps)
     ev1.record()
+    enq = time.perf_counter() - t0                 # host time to enqueue the K steps (must stay below the device time)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -150,12 +164,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.obs_f32 else "u8", "data": "synthetic",
             "config": {"workload": "%s %dx%d, %d agents, %d envs per GPU, uniform random actions, reset every %d steps"
                                    % (args.game, eng.H, eng.W, n_agents, E, HORIZON),
-                       "envs_per_gpu": E, "agents": n_agents, "obs": ("float32" if args.obs_f32 else "uint8") + " [E,N,15,15,3]", "launches_per_step": 1,
+                       "envs_per_gpu": E, "agents": n_agents, "obs": ("float32" if args.obs_f32 else "uint8") + " [E,N,15,15,3]", "launches_per_step": 1, "enqueue": "ssd_rollout_random" if use_rollout else "one call per step",
                        "gather": do_gather, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "ssd::ssd_env_kernel<%d, 0, %s, ...>" % (game, "true" if args.obs_f32 else "false"), "bytes_per_env_step": bytes_env,
-                         "avg_launch_us": launch_us},
+                         "avg_launch_us": launch_us, "host_enqueue_us_per_step": enq * 1e6 / args.steps},
         }
         # HBM bytes per launch from the PMC counters of the committed profile of this exact workload
         # (tools/profile_gpu.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE correction)

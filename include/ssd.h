@@ -105,6 +105,16 @@ int ssd_step(ssd_env *env, const int32_t *actions, const uint8_t *order, void *o
 int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, void *obs, int32_t *rew,
                     uint8_t *done, uint32_t flags, void *stream);
 
+/* A whole random-action rollout (rollout.py:58-70: reset, then `horizon` steps of uniformly drawn actions) enqueued
+ * by ONE call: n_steps launches of the step kernel, preceded by a full reset whenever (step0 + k) % reset_every == 0
+ * (reset_every = 0: never).  Step k writes slot (step0 + k) % ring of obs [ring,E,N,V,V,3], rew [ring,E,N] and
+ * done [ring,E,N] (ring = 1: every step overwrites the same buffers); any of the three may be NULL.  Device pointers
+ * only; the call enqueues on `stream` and returns.  Exactly the launches that n_steps calls of ssd_step_random (and
+ * ssd_reset) would make -- the point is the host: one library call instead of one per step keeps a launch-bound
+ * rollout fed. */
+int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32_t reset_every, int32_t step0,
+                       void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream);
+
 /* Observation of the current state without stepping (the per-agent part of map_env.py:189-199). */
 int ssd_observe(ssd_env *env, void *obs, uint32_t flags, void *stream);
 

@@ -123,7 +123,10 @@ int ensure_staging(ssd_env *env) {
 int run(ssd_env *env, int mode, const int32_t *actions, const uint8_t *order, const uint8_t *mask,
         int num_actions_random, int32_t *actions_out, void *obs_v, int32_t *rew, uint8_t *done, int rotate,
         uint32_t flags, void *stream) {
-    SSD_HIP(env, hipSetDevice(env->device));
+    {   // the stepping calls are launch-bound on the host: only switch devices when the thread is on another one
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != env->device) SSD_HIP(env, hipSetDevice(env->device));
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t en = (size_t)env->E * env->N;
     const bool host = (flags & SSD_HOST_PTRS) != 0, f32 = (flags & SSD_OBS_F32) != 0;
@@ -344,6 +347,25 @@ int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, voi
     const int na = env->game == SSD_GAME_HARVEST ? 8 : 9;
     if (num_actions < 1 || num_actions > na) { env->err = "num_actions outside the game's Discrete(n)"; return SSD_E_INVALID; }
     return run(env, ssd::kModeStep, nullptr, nullptr, nullptr, num_actions, actions_out, obs, rew, done, 1, flags, stream);
+}
+
+int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32_t reset_every, int32_t step0,
+                       void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream) {
+    if (!env || n_steps < 0 || reset_every < 0 || step0 < 0 || ring < 1) return SSD_E_INVALID;
+    if (flags & SSD_HOST_PTRS) { env->err = "ssd_rollout_random takes device pointers"; return SSD_E_INVALID; }
+    const int na = env->game == SSD_GAME_HARVEST ? 8 : 9;
+    if (num_actions < 1 || num_actions > na) { env->err = "num_actions outside the game's Discrete(n)"; return SSD_E_INVALID; }
+    const size_t en = (size_t)env->E * env->N, ob = obs_bytes(env, (flags & SSD_OBS_F32) != 0);
+    for (int k = 0; k < n_steps; ++k) {
+        const size_t slot = (size_t)((step0 + k) % ring);
+        uint8_t *o = obs ? static_cast<uint8_t *>(obs) + slot * ob : nullptr;
+        int rc;
+        if (reset_every > 0 && (step0 + k) % reset_every == 0)
+            if ((rc = run(env, ssd::kModeReset, nullptr, nullptr, nullptr, 0, nullptr, o, nullptr, nullptr, 0, flags, stream))) return rc;
+        if ((rc = run(env, ssd::kModeStep, nullptr, nullptr, nullptr, num_actions, nullptr, o, rew ? rew + slot * en : nullptr,
+                      done ? done + slot * en : nullptr, 1, flags, stream))) return rc;
+    }
+    return SSD_OK;
 }
 
 int ssd_observe(ssd_env *env, void *obs, uint32_t flags, void *stream) {

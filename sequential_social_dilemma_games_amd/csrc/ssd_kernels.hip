@@ -385,11 +385,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
             // whatever the shuffle says (STAY / wall-blocked movers target their own cell and stay), and
             // since draws are counter-keyed there is no RNG state to advance.  Otherwise run the
             // reference algorithm in full.
-            uint64_t clashm = 0;                             // lanes whose target is agent j's cell or mover j's target, j != lane
+            const uint64_t agents_m = N >= 64 ? ~0ull : bit((uint32_t)N) - 1;
+            uint64_t clashm = 0, dupm = 0;                   // lanes (!= j) whose target is agent j's cell or mover j's target
             for (int j = 0; j < N; ++j) {
                 const uint32_t cj = rl(cell, j), tj = rl(tcell, j);
-                const uint64_t on_cell = ballot(tcell == cj), on_target = ballot(tcell == tj);
-                clashm |= (on_cell | (((M >> j) & 1) ? on_target : 0ull)) & ~bit(j);
+                const uint64_t on_cell = ballot(tcell == cj), on_target = (((M >> j) & 1) ? ballot(tcell == tj) : 0ull) & ~bit(j);
+                clashm |= (on_cell & ~bit(j)) | on_target;
+                dupm |= on_target;
             }
             const bool slow = (clashm & M) != 0;
             SSD_NOTE(12, slow ? 1 : 0);
@@ -397,61 +399,88 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 if (mover) cell = tcell;
             } else {                                         // :415 (M != 0 here)
                 __builtin_amdgcn_s_setprio(3);               // the slowest waves of a launch come through here (1-2 % of the envs)
-                const int nm = __builtin_popcountll(M);
-                uint32_t perm = 0;                           // lane k: k-th entry of the (shuffled) zipped list
-                {
-                    int cnt = 0;
-                    for (int k = 0; k < nord; ++k) {
-                        const uint32_t a = rl(ordv, k);
-                        if ((M >> a) & 1) { if (lane == cnt) perm = a; ++cnt; }
-                    }
-                }
-                const uint32_t pk = phase_key(key, t, kMove);
-                for (int i = nm - 1; i >= 1; --i) {          // :421-423 np.random.shuffle = Fisher-Yates from the end
-                    const uint32_t j = randint(draw(pk, (uint32_t)i), (uint32_t)i + 1);
-                    const uint32_t vi = rl(perm, i), vj = rl(perm, j);
-                    if (lane == i) perm = vj;
-                    if (lane == (int)j) perm = vi;
-                }
                 uint64_t Hm = M;                             // ids that still have an entry in agent_moves
-                // :424-491 cells wanted by several agents, in lexicographic order (np.unique, axis=0).
-                // Contested targets are rare: find them with one pass of lane compares, then visit them
-                // in ascending cell order (scalar min over the few lanes involved).
-                bool dup = false;
-                for (uint64_t m = M; m; m &= m - 1) {
-                    const int j = __builtin_ctzll(m);
-                    dup |= mover && j != lane && rl(tcell, j) == tcell;
-                }
-                uint64_t todo = ballot(dup);
-                while (todo) {
-                    uint32_t nxt = 0xFFFFFFFFu;
-                    for (uint64_t m = todo; m; m &= m - 1) nxt = umin(nxt, rl(tcell, __builtin_ctzll(m)));
-                    const uint64_t Cm = ballot(mover && tcell == nxt);              // contenders (:441-442)
-                    todo &= ~Cm;
-                    bool cell_free = true;
-                    const uint64_t Pm = ballot(is_agent && cell == nxt);            // :449 move in self.agent_pos
-                    if (Pm) {
-                        const uint32_t occ = 63 - __builtin_clzll(Pm);              // agent_by_pos: last index wins
-                        const uint32_t occ_mv = rl(mvcell, occ);
-                        if ((Cm >> occ) & 1) cell_free = false;                     // (1) :460
-                        else if (!((Hm >> occ) & 1) || occ_mv == nxt) cell_free = false;    // (2) :466-468
-                        else if (ballot(((Cm >> lane) & 1) && cell == occ_mv)) cell_free = false; // (3) :472-476
+                // :424-491 cells wanted by several agents, in lexicographic order (np.unique, axis=0): visited in
+                // ascending cell order (scalar min over the few lanes involved).  The shuffle of :421-423 only
+                // decides who wins such a cell, so it is only computed when there is one (draws are counter-keyed).
+                uint64_t todo = dupm & M;
+                if (todo) {
+                    const int nm = __builtin_popcountll(M);
+                    uint32_t perm = 0;                       // lane k: k-th entry of the (shuffled) zipped list
+                    {
+                        int cnt = 0;
+                        for (int k = 0; k < nord; ++k) {
+                            const uint32_t a = has_order ? rl(ordv, k) : (uint32_t)k;
+                            if ((M >> a) & 1) { if (lane == cnt) perm = a; ++cnt; }
+                        }
                     }
-                    if (cell_free) {                         // :480-483 first contender in shuffled order moves NOW
-                        uint32_t w = 0;
-                        for (int k = 0; k < nm; ++k) { w = rl(perm, k); if ((Cm >> w) & 1) break; }
-                        if (lane == (int)w) cell = nxt;
+                    const uint32_t pk = phase_key(key, t, kMove);
+                    for (int i = nm - 1; i >= 1; --i) {      // :421-423 np.random.shuffle = Fisher-Yates from the end
+                        const uint32_t j = randint(draw(pk, (uint32_t)i), (uint32_t)i + 1);
+                        const uint32_t vi = rl(perm, i), vj = rl(perm, j);
+                        if (lane == i) perm = vj;
+                        if (lane == (int)j) perm = vi;
                     }
-                    if ((Cm >> lane) & 1) mvcell = cell;     // :486-491 every contender's move becomes "stay"
+                    while (todo) {
+                        uint32_t nxt = 0xFFFFFFFFu;
+                        for (uint64_t m = todo; m; m &= m - 1) nxt = umin(nxt, rl(tcell, __builtin_ctzll(m)));
+                        const uint64_t Cm = ballot(mover && tcell == nxt);          // contenders (:441-442)
+                        todo &= ~Cm;
+                        bool cell_free = true;
+                        const uint64_t Pm = ballot(is_agent && cell == nxt);        // :449 move in self.agent_pos
+                        if (Pm) {
+                            const uint32_t occ = 63 - __builtin_clzll(Pm);          // agent_by_pos: last index wins
+                            const uint32_t occ_mv = rl(mvcell, occ);
+                            if ((Cm >> occ) & 1) cell_free = false;                 // (1) :460
+                            else if (!((Hm >> occ) & 1) || occ_mv == nxt) cell_free = false;    // (2) :466-468
+                            else if (ballot(__builtin_amdgcn_inverse_ballot_w64(Cm) && cell == occ_mv)) cell_free = false; // (3) :472-476
+                        }
+                        if (cell_free) {                     // :480-483 first contender in shuffled order moves NOW
+                            uint32_t w = 0;
+                            for (int k = 0; k < nm; ++k) { w = rl(perm, k); if ((Cm >> w) & 1) break; }
+                            if (lane == (int)w) cell = nxt;
+                        }
+                        if (__builtin_amdgcn_inverse_ballot_w64(Cm)) mvcell = cell;   // :486-491 every contender's move becomes "stay"
+                    }
                 }
-                // :494-543 remaining moves: chains, swaps, cycles
+                // :494-543 remaining moves: chains, swaps, cycles.  Who stands on each agent's target, and does any cell
+                // hold two agents (possible after a contested cell was entered while its occupant was still there)?
+                uint64_t overlap = 0;
+                int occ_of_target = -1;
+                for (int j = 0; j < N; ++j) {
+                    const uint32_t cj = rl(cell, j);
+                    occ_of_target = (mvcell == cj) ? j : occ_of_target;
+                    overlap |= ballot(cell == cj) & agents_m & ~bit(j);
+                }
+                if (!overlap) {
+                    // Usual case: every cell holds at most one agent and (after the step above) no two pending moves
+                    // share a target, so "a waits for the agent on its target" is a graph of disjoint paths and cycles,
+                    // and the pass loop of :494-543 comes out as: a path moves as a whole iff its head's target is free;
+                    // it stays as a whole if it ends at an agent that is not moving; a 2-cycle (swap, :524-530) stays;
+                    // longer cycles rotate (:540-543).  Resolved by pointer jumping over lanes, ceil(log2 N) rounds.
+                    const bool pend = __builtin_amdgcn_inverse_ballot_w64(Hm) & (mvcell != cell);
+                    int st = pend ? (occ_of_target < 0 ? 1 : 2) : 0;                // 0 stays, 1 moves, 2 waits for lane `nx`
+                    const int nx0 = (occ_of_target & 63) << 2;
+                    int nx = nx0;
+                    for (int r = 1; r < N; r <<= 1) {
+                        const int s2 = __builtin_amdgcn_ds_bpermute(nx, st), n2 = __builtin_amdgcn_ds_bpermute(nx, nx);
+                        const bool waiting = st == 2;
+                        st = (waiting & (s2 != 2)) ? s2 : st;
+                        nx = (waiting & (s2 == 2)) ? n2 : nx;
+                    }
+                    if (ballot(st == 2)) {                                          // still waiting: on a cycle
+                        const int back = __builtin_amdgcn_ds_bpermute(nx0, nx0);    // my target's target ...
+                        st = st == 2 ? (back == (lane << 2) ? 0 : 1) : st;          // ... is me: a swap
+                    }
+                    if (st == 1) cell = mvcell;
+                } else
                 while (Hm) {
                     const uint32_t snap_cell = cell, snap_mv = mvcell;              // agent_by_pos (:495), moves_copy (:498)
                     const uint64_t snapH = Hm;
                     uint64_t del = 0;
                     const int n0 = __builtin_popcountll(Hm);
                     for (int k = 0; k < nord; ++k) {                                // agent_moves insertion order = action order
-                        const uint32_t a = rl(ordv, k);
+                        const uint32_t a = has_order ? rl(ordv, k) : (uint32_t)k;
                         if (!((snapH >> a) & 1) || ((del >> a) & 1)) continue;      // :500-502
                         const uint32_t m = rl(snap_mv, a);
                         if (ballot(is_agent && cell == m)) {                        // :503 (live positions)
@@ -472,7 +501,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                         }
                     }
                     if (__builtin_popcountll(Hm) == n0) {    // :540-543 only cycles are left: rotate them
-                        if ((Hm >> lane) & 1) cell = mvcell;
+                        if (__builtin_amdgcn_inverse_ballot_w64(Hm)) cell = mvcell;
                         break;
                     }
                 }

@@ -54,6 +54,8 @@ class VecEngine(object):
         L = _capi.lib()
         _capi.check(L.ssd_create(C.byref(c), C.byref(self._h)))
         self._L = L
+        self._out_cache = (None, None)               # (outputs tuple, its pointers) of the last step_random call
+        self._torch_dev = None
         if L.ssd_potential_waste_area(self._h) != self.potential_waste_area:
             raise _capi.SsdError("potential_waste_area mismatch between host and library")
 
@@ -70,11 +72,17 @@ class VecEngine(object):
 
     # ------------------------------------------------------------------ device-tensor API
     def _torch(self):
-        import torch
-        return torch, torch.device("cuda", self.device)
+        if self._torch_dev is None:
+            import torch
+            self._torch_dev = (torch, torch.device("cuda", self.device))
+        return self._torch_dev
 
     def _stream(self):
+        """torch's current stream on the engine's device (what the kernels are enqueued on)."""
         torch, dev = self._torch()
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)     # the cheap way; the public API builds a Stream object
+        if raw is not None:
+            return C.c_void_p(raw(dev.index if dev.index is not None else torch.cuda.current_device()))
         return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     def alloc_outputs(self, float32=False):
@@ -129,11 +137,37 @@ class VecEngine(object):
 
     def step_random(self, out=None, actions_out=None, num_actions=None):
         """One step with uniform random actions drawn on the device (rollout.py:62-70)."""
-        obs, rew, done = out if out is not None else self.alloc_outputs()
+        if out is not None and out is self._out_cache[0]:                  # same buffers as last time: pointers are known
+            obs, rew, done = out
+            po, pr, pd, fl = self._out_cache[1]
+        else:
+            obs, rew, done = out if out is not None else self.alloc_outputs()
+            po, pr, pd, fl = self._dp(obs), self._dp(rew), self._dp(done), self._obs_flags(obs)
+            self._out_cache = (out, (po, pr, pd, fl))
         na = self.num_actions if num_actions is None else int(num_actions)
-        _capi.check(self._L.ssd_step_random(self._h, na, self._dp(actions_out), self._dp(obs), self._dp(rew),
-                                            self._dp(done), self._obs_flags(obs), self._stream()), self._h)
+        rc = self._L.ssd_step_random(self._h, na, self._dp(actions_out), po, pr, pd, fl, self._stream())
+        if rc:
+            _capi.check(rc, self._h)
         return obs, rew, done
+
+    def rollout_random(self, n_steps, obs, rew=None, done=None, reset_every=0, step0=0, num_actions=None):
+        """rollout.py:58-70 as ONE library call: `n_steps` random-action steps (plus a full reset whenever
+        (step0 + k) % reset_every == 0) enqueued back to back.  obs / rew / done are device tensors with a leading ring
+        dimension R: step k writes slot (step0 + k) % R  (obs u8 or f32 [R,E,N,V,V,3], rew i32 [R,E,N], done u8 [R,E,N]).
+        Same launches as n_steps calls of step_random(); the host just stops being the bottleneck."""
+        torch, dev = self._torch()
+        ring = int(obs.shape[0])
+        if obs.dtype not in (torch.uint8, torch.float32):
+            raise ValueError("obs must be uint8 or float32")
+        self._check_tensor(obs, (ring, self.E, self.N, self.V, self.V, 3), obs.dtype, "obs")
+        if rew is not None:
+            self._check_tensor(rew, (ring, self.E, self.N), torch.int32, "rew")
+        if done is not None:
+            self._check_tensor(done, (ring, self.E, self.N), torch.uint8, "done")
+        na = self.num_actions if num_actions is None else int(num_actions)
+        _capi.check(self._L.ssd_rollout_random(self._h, na, int(n_steps), int(reset_every), int(step0), self._dp(obs), self._dp(rew),
+                                               self._dp(done), ring, _capi.SSD_OBS_F32 if obs.dtype == torch.float32 else 0,
+                                               self._stream()), self._h)
 
     def observe(self, rotate=True, obs=None):
         torch, dev = self._torch()

@@ -374,3 +374,35 @@ def test_float32_observation_mode_is_the_cast_of_the_reference_float64():
         a.reset(mask=mask, obs=fa[0]); b.reset(mask=mask, obs=ub[0])
         same(fa[0][mask.bool()], ub[0][mask.bool()])
         assert torch.equal(fa[0][~mask.bool()], before[~mask.bool()])          # rows of envs that were not reset stay
+
+
+@pytest.mark.parametrize("game", [K.GAME_HARVEST, K.GAME_CLEANUP])
+def test_rollout_random_is_the_same_launches_as_step_by_step(game):
+    """ssd_rollout_random (one library call for a whole random-action rollout, rollout.py:58-70) against the oracle
+    stepped one call at a time: every ring slot holds the observations / rewards of its step, a reset happens every
+    `reset_every` steps, and a second call continues where the first stopped (step0)."""
+    import torch
+    E, N, ring, every = 96, 5, 4, 7
+    eng = VecEngine(game, None, num_envs=E, num_agents=N, seed=11)
+    ora = pyoracle.Oracle(game, K.HARVEST_MAP if game == K.GAME_HARVEST else K.CLEANUP_MAP, E, N, G.default_lut(), seed=11)
+    obs = torch.zeros((ring, E, N, 15, 15, 3), dtype=torch.uint8, device="cuda")
+    rew = torch.zeros((ring, E, N), dtype=torch.int32, device="cuda")
+    done = torch.zeros((ring, E, N), dtype=torch.uint8, device="cuda")
+    want = {}
+    for k in range(23):
+        if k % every == 0:
+            ora.reset()
+        _, o_obs, o_rew, _ = ora.step_random()
+        want[k] = (o_obs, o_rew)
+    eng.rollout_random(10, obs, rew, done, reset_every=every, step0=0)
+    eng.rollout_random(13, obs, rew, done, reset_every=every, step0=10)
+    got_obs, got_rew = obs.cpu().numpy(), rew.cpu().numpy()
+    for k in range(23 - ring, 23):                              # the last `ring` steps are still in the ring
+        np.testing.assert_array_equal(got_obs[k % ring], want[k][0], err_msg="obs of step %d" % k)
+        np.testing.assert_array_equal(got_rew[k % ring], want[k][1], err_msg="rew of step %d" % k)
+    a, b = eng.get_state(), ora.get_state()
+    for key in ("world", "pos", "orient", "episode", "t"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert not done.any().item() and eng.status() == 0
+    with pytest.raises(ValueError):
+        eng.rollout_random(1, obs[:, :1], rew, done)
