@@ -199,6 +199,9 @@ __host__ int envs_per_block(const Params &p, bool f32) {
 template <int GAME, int MODE, bool F32, int NA, bool STD, bool FAST>
 __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Params p) {
     extern __shared__ __align__(16) uint8_t smem[];
+#ifdef SSD_STAMPS
+    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();    // before the first kernel-argument fetch
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index and everything derived from it (env index, LDS region, global offsets) is wave-uniform:
     // say so, and the per-env address arithmetic runs on the scalar unit instead of as 64-bit VALU multiplies
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
     bool active = e < p.E;                                   // wave-uniform
     if (active && mode == kModeReset && p.mask) active = p.mask[e] != 0;
     SSD_STAMP_RT(10);
+    SSD_NOTE(14, t_entry);
     SSD_STAMP(0);
 
     if (active) {
@@ -826,7 +830,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
         if (p.obs) {
             typedef __attribute__((address_space(3))) const uint8_t lds_u8;
             const int V = STD ? 15 : p.V, v = STD ? 7 : p.view_len, VV = V * V;
-            uint8_t *out_env = p.obs + (size_t)e * N * VV * 3;
+            // (diagnostic builds, skip bit 4: all envs write the first 64 envs' blocks -- same instructions, no HBM write stream)
+            uint8_t *out_env = p.obs + (size_t)(SSD_SKIP(4) ? (e & 63) : e) * N * VV * 3;
             // Per-agent constants, computed once with lane = agent and read back as scalars in the loop.
             // Window cell (a, b) of an agent on grid cell `cell` is grid cell cell + (a - v) * WP + (b - v).
             // The view is rot90^k of the window (rotate_view, map_env.py:669-689; UP 0, LEFT 1, DOWN 2,
@@ -860,6 +865,48 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 uint32_t off3 = (uint32_t)pp0 * 3u;                                 // byte offset of the lane's cells in an agent's block
                 asm volatile("" : "+v"(off3));                                      // keep it in a register (else re-derived per agent)
                 const int ncell = lane_on ? VV - pp0 : 0;                           // >= 4 whenever VV >= 4
+                if (STD && NA > 0 && NA % 5 == 0 && !F32) {
+                    // Specialised kernels: five agents per pass.  All their grid reads go out together, then all the
+                    // colour-table reads, then the stores: two LDS round trips per pass instead of two per agent.
+                    constexpr int kB = 5;
+                    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                    struct __attribute__((packed, aligned(1))) P3 { u32x3 v; };
+                    for (int ag0 = 0; ag0 < NA; ag0 += kB) {
+                        uint32_t addr[kB][4], px[kB][4];
+#pragma unroll
+                        for (int u = 0; u < kB; ++u) {
+                            const uint32_t k = rl(a_k, ag0 + u);
+                            const uint32_t s0 = rl(a_s0, ag0 + u) + world_lds;
+                            const int sgn = k >= 2 ? -1 : 1;
+                            if (k & 1) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[u][q]) : "v"(L1[q]), "v"(sgn), "s"(s0));
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[u][q]) : "v"(L0[q]), "v"(sgn), "s"(s0));
+                            }
+                        }
+                        uint32_t gl[kB][4];
+#pragma unroll
+                        for (int u = 0; u < kB; ++u)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) gl[u][q] = *(lds_u8 *)(uintptr_t)addr[u][q];
+#pragma unroll
+                        for (int u = 0; u < kB; ++u)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) px[u][q] = s_lut[gl[u][q]];
+                        if (lane_on) {
+#pragma unroll
+                            for (int u = 0; u < kB; ++u) {
+                                u32x3 d;
+                                d.x = __builtin_amdgcn_perm(px[u][1], px[u][0], 0x04020100u);   // r0 g0 b0 r1
+                                d.y = __builtin_amdgcn_perm(px[u][2], px[u][1], 0x05040201u);   // g1 b1 r2 g2
+                                d.z = __builtin_amdgcn_perm(px[u][3], px[u][2], 0x06050402u);   // b2 r3 g3 b3
+                                reinterpret_cast<P3 *>(out_env + (size_t)(ag0 + u) * VV * 3 + off3)->v = d;
+                            }
+                        }
+                    }
+                } else
                 for (int ag = 0; ag < N; ++ag) {
                     const uint32_t k = rl(a_k, ag);
                     const uint32_t s0 = rl(a_s0, ag) + world_lds;

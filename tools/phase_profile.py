@@ -70,6 +70,8 @@ def main():
         print("    %-13s phases (cycles): " % name + " ".join("%s %.0f" % (n.split()[0], v) for n, v in zip(NAMES, d_last[sel].mean(dim=0).tolist()) if n != "wg barrier")
               + " | starts %.2f us" % float(starts[sel].mean()))
     # position of the wave among the waves of its SIMD: envs e, e+? share a SIMD -- unknown mapping; report by end rank instead
+    print("    wave entry -> first stamp (kernel-argument fetch): mean %.2f us, max %.2f us" % (
+        float(((s[:, 10] - s[:, 14]) * 0.01).mean()), float(((s[:, 10] - s[:, 14]) * 0.01).max())))
     order = dur.sort().values
     print("    duration percentiles (us): " + " / ".join("%.2f" % float(order[int(q * (E - 1))]) for q in (0, 0.1, 0.5, 0.9, 0.99, 1.0)))
     tot = float(acc.sum())
