@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="RCCL all-gather of obs/rew after every step")
     ap.add_argument("--obs-f32", action="store_true", help="separate mode: the kernel writes float32 observations (4x the obs bytes)")
     ap.add_argument("--per-step-calls", action="store_true", help="one Python call per step instead of ssd_rollout_random")
+    ap.add_argument("--chains", type=int, default=0, help="env ranges stepped concurrently by ssd_rollout_random (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -117,6 +118,10 @@ def main():
     # chunk instead of one Python call per step, so that the host never starves the 9 us kernels.
     ring = tuple(t.unsqueeze(0) for t in out)
     use_rollout = not (do_gather or args.per_step_calls)
+    chains = 1
+    if use_rollout:                                # env ranges the library steps on streams of its own (envs are independent)
+        chains = args.chains if args.chains > 0 else (2 if E >= 2048 else 1)
+        eng.set_rollout_chains(chains)
 
     def run_steps(k0, n):
         if use_rollout:
@@ -164,12 +169,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.obs_f32 else "u8", "data": "synthetic",
             "config": {"workload": "%s %dx%d, %d agents, %d envs per GPU, uniform random actions, reset every %d steps"
                                    % (args.game, eng.H, eng.W, n_agents, E, HORIZON),
-                       "envs_per_gpu": E, "agents": n_agents, "obs": ("float32" if args.obs_f32 else "uint8") + " [E,N,15,15,3]", "launches_per_step": 1, "enqueue": "ssd_rollout_random" if use_rollout else "one call per step",
+                       "envs_per_gpu": E, "agents": n_agents, "obs": ("float32" if args.obs_f32 else "uint8") + " [E,N,15,15,3]", "launches_per_step": chains, "enqueue": ("ssd_rollout_random, %d chain(s) of %d envs" % (chains, E // chains)) if use_rollout else "one call per step",
                        "gather": do_gather, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "ssd::ssd_env_kernel<%d, 0, %s, ...>" % (game, "true" if args.obs_f32 else "false"), "bytes_per_env_step": bytes_env,
-                         "avg_launch_us": launch_us, "host_enqueue_us_per_step": enq * 1e6 / args.steps},
+                         "avg_launch_us": launch_us, "concurrent_launches": chains, "host_enqueue_us_per_step": enq * 1e6 / args.steps},
         }
         # HBM bytes per launch from the PMC counters of the committed profile of this exact workload
         # (tools/profile_gpu.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE correction)

@@ -111,9 +111,14 @@ int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, voi
  * done [ring,E,N] (ring = 1: every step overwrites the same buffers); any of the three may be NULL.  Device pointers
  * only; the call enqueues on `stream` and returns.  Exactly the launches that n_steps calls of ssd_step_random (and
  * ssd_reset) would make -- the point is the host: one library call instead of one per step keeps a launch-bound
- * rollout fed. */
+ * rollout fed.  Envs are independent, so the library may split the batch into up to 8 env ranges ("chains") that it
+ * enqueues on streams of its own, forked from and joined back into `stream`: the launches of one chain then overlap
+ * the dispatch / drain gaps of the others.  Results do not depend on the number of chains. */
 int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32_t reset_every, int32_t step0,
                        void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream);
+
+/* Number of chains ssd_rollout_random uses: 1..8, or 0 = automatic (2 from 2048 envs on, else 1). */
+int ssd_set_rollout_chains(ssd_env *env, int32_t chains);
 
 /* Observation of the current state without stepping (the per-agent part of map_env.py:189-199). */
 int ssd_observe(ssd_env *env, void *obs, uint32_t flags, void *stream);

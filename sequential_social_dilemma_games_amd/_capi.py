@@ -16,7 +16,7 @@ SSD_ST_BAD_ACTION, SSD_ST_NO_SPAWN, SSD_ST_MOVE_LOOKUP = 1, 2, 4
 ABI_VERSION = 1
 
 # every symbol include/ssd.h declares
-SYMBOLS = ("ssd_create", "ssd_destroy", "ssd_reset", "ssd_step", "ssd_step_random", "ssd_rollout_random", "ssd_observe",
+SYMBOLS = ("ssd_create", "ssd_destroy", "ssd_reset", "ssd_step", "ssd_step_random", "ssd_rollout_random", "ssd_set_rollout_chains", "ssd_observe",
            "ssd_get_state", "ssd_set_state", "ssd_get_waste_count", "ssd_render_full", "ssd_set_horizon", "ssd_potential_waste_area",
            "ssd_device_status", "ssd_synchronize", "ssd_last_error", "ssd_abi_version")
 
@@ -79,6 +79,7 @@ def lib():
         L.ssd_step.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp]
         L.ssd_step_random.argtypes = [vp, i32, vp, vp, vp, vp, u32, vp]
         L.ssd_rollout_random.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, i32, u32, vp]
+        L.ssd_set_rollout_chains.argtypes = [vp, i32]
         L.ssd_observe.argtypes = [vp, vp, u32, vp]
         L.ssd_get_state.argtypes = [vp] + [vp] * 6
         L.ssd_set_state.argtypes = [vp] + [vp] * 6

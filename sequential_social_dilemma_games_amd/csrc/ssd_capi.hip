@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ssd.h"
@@ -29,6 +30,11 @@ struct ssd_env {
     int32_t *st_actions = nullptr, *st_rew = nullptr, *st_actions_out = nullptr;
     float *st_obs_f32 = nullptr;
     uint8_t *st_order = nullptr, *st_obs = nullptr, *st_done = nullptr, *st_mask = nullptr, *st_rgb = nullptr;
+    // ssd_rollout_random: extra chains (streams + fork / join events), created on first use
+    std::vector<hipStream_t> chain_streams;
+    std::vector<hipEvent_t> chain_events;
+    hipEvent_t fork_event = nullptr;
+    int rollout_chains = 0;           // 0 = automatic
     std::string err;
 };
 
@@ -325,6 +331,9 @@ int ssd_destroy(ssd_env *env) {
     (void)hipSetDevice(env->device);
     (void)hipDeviceSynchronize();
     for (void *ptr : env->allocs) (void)hipFree(ptr);
+    for (hipStream_t cs : env->chain_streams) (void)hipStreamDestroy(cs);
+    for (hipEvent_t ce : env->chain_events) (void)hipEventDestroy(ce);
+    if (env->fork_event) (void)hipEventDestroy(env->fork_event);
     delete env;
     return SSD_OK;
 }
@@ -349,22 +358,78 @@ int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, voi
     return run(env, ssd::kModeStep, nullptr, nullptr, nullptr, num_actions, actions_out, obs, rew, done, 1, flags, stream);
 }
 
+// One chain of a rollout: the launches of steps [0, n_steps) for envs [e_begin, e_end), enqueued on `s`.
+static int rollout_chain(ssd_env *env, int e_begin, int e_end, int32_t num_actions, int32_t n_steps, int32_t reset_every,
+                         int32_t step0, uint8_t *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, hipStream_t s) {
+    if (hipSetDevice(env->device) != hipSuccess) return SSD_E_DEVICE;
+    const bool f32 = (flags & SSD_OBS_F32) != 0;
+    const size_t en = (size_t)env->E * env->N, ob = obs_bytes(env, f32);
+    Params p = env->p;
+    p.obs_f32 = f32 ? 1 : 0;
+    p.e_begin = e_begin; p.E = e_end;
+    for (int k = 0; k < n_steps; ++k) {
+        const size_t slot = (size_t)((step0 + k) % ring);
+        p.obs = obs ? obs + slot * ob : nullptr;
+        if (reset_every > 0 && (step0 + k) % reset_every == 0) {
+            p.mode = ssd::kModeReset; p.rotate = 0; p.num_actions_random = 0; p.rew = nullptr; p.done = nullptr;
+            ssd::launch(p, env->game, s);
+        }
+        p.mode = ssd::kModeStep; p.rotate = 1; p.num_actions_random = num_actions;
+        p.rew = rew ? rew + slot * en : nullptr; p.done = done ? done + slot * en : nullptr;
+        ssd::launch(p, env->game, s);
+    }
+    return hipGetLastError() == hipSuccess ? SSD_OK : SSD_E_DEVICE;
+}
+
 int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32_t reset_every, int32_t step0,
                        void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream) {
     if (!env || n_steps < 0 || reset_every < 0 || step0 < 0 || ring < 1) return SSD_E_INVALID;
     if (flags & SSD_HOST_PTRS) { env->err = "ssd_rollout_random takes device pointers"; return SSD_E_INVALID; }
     const int na = env->game == SSD_GAME_HARVEST ? 8 : 9;
     if (num_actions < 1 || num_actions > na) { env->err = "num_actions outside the game's Discrete(n)"; return SSD_E_INVALID; }
-    const size_t en = (size_t)env->E * env->N, ob = obs_bytes(env, (flags & SSD_OBS_F32) != 0);
-    for (int k = 0; k < n_steps; ++k) {
-        const size_t slot = (size_t)((step0 + k) % ring);
-        uint8_t *o = obs ? static_cast<uint8_t *>(obs) + slot * ob : nullptr;
-        int rc;
-        if (reset_every > 0 && (step0 + k) % reset_every == 0)
-            if ((rc = run(env, ssd::kModeReset, nullptr, nullptr, nullptr, 0, nullptr, o, nullptr, nullptr, 0, flags, stream))) return rc;
-        if ((rc = run(env, ssd::kModeStep, nullptr, nullptr, nullptr, num_actions, nullptr, o, rew ? rew + slot * en : nullptr,
-                      done ? done + slot * en : nullptr, 1, flags, stream))) return rc;
+    if (obs && (reinterpret_cast<uintptr_t>(obs) & 3u)) { env->err = "obs must be 4-byte aligned"; return SSD_E_INVALID; }
+    SSD_HIP(env, hipSetDevice(env->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint8_t *o = static_cast<uint8_t *>(obs);
+    // Envs are independent, so a rollout is as many independent launch chains as we like.  Two chains on two streams
+    // (each enqueued by its own host thread) keep the GPU busy while the other chain's kernel drains and the next one is
+    // dispatched -- the ~2 us per launch that a single chain of 9 us kernels cannot hide.  SSD_ROLLOUT_CHAINS overrides.
+    static const int forced = [] { const char *v = getenv("SSD_ROLLOUT_CHAINS"); return v ? atoi(v) : 0; }();
+    int chains = env->rollout_chains > 0 ? env->rollout_chains : forced > 0 ? forced : (env->E >= 2048 && n_steps >= 16 ? 2 : 1);
+    if (chains > 8) chains = 8;
+    if (chains > env->E) chains = env->E;
+    if (chains <= 1) {
+        int rc = rollout_chain(env, 0, env->E, num_actions, n_steps, reset_every, step0, o, rew, done, ring, flags, s);
+        if (rc) env->err = "kernel launch failed in ssd_rollout_random";
+        return rc;
     }
+    while ((int)env->chain_streams.size() < chains - 1) {
+        hipStream_t ns; hipEvent_t ne;
+        SSD_HIP(env, hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+        SSD_HIP(env, hipEventCreateWithFlags(&ne, hipEventDisableTiming));
+        env->chain_streams.push_back(ns); env->chain_events.push_back(ne);
+    }
+    if (!env->fork_event) SSD_HIP(env, hipEventCreateWithFlags(&env->fork_event, hipEventDisableTiming));
+    // fork: the extra chains start after whatever the caller's stream holds so far
+    SSD_HIP(env, hipEventRecord(env->fork_event, s));
+    for (int c = 1; c < chains; ++c) SSD_HIP(env, hipStreamWaitEvent(env->chain_streams[c - 1], env->fork_event, 0));
+    std::vector<int> rcs(chains, SSD_OK);
+    std::vector<std::thread> workers;
+    auto range = [&](int c) { return (int)(((long long)env->E * c) / chains); };
+    for (int c = 1; c < chains; ++c)
+        workers.emplace_back([&, c] {
+            rcs[c] = rollout_chain(env, range(c), range(c + 1), num_actions, n_steps, reset_every, step0, o, rew, done, ring, flags,
+                                   env->chain_streams[c - 1]);
+        });
+    rcs[0] = rollout_chain(env, range(0), range(1), num_actions, n_steps, reset_every, step0, o, rew, done, ring, flags, s);
+    for (auto &w : workers) w.join();
+    // join: the caller's stream continues after every chain
+    for (int c = 1; c < chains; ++c) {
+        SSD_HIP(env, hipEventRecord(env->chain_events[c - 1], env->chain_streams[c - 1]));
+        SSD_HIP(env, hipStreamWaitEvent(s, env->chain_events[c - 1], 0));
+    }
+    for (int c = 0; c < chains; ++c)
+        if (rcs[c]) { env->err = "kernel launch failed in ssd_rollout_random"; return rcs[c]; }
     return SSD_OK;
 }
 
@@ -502,6 +567,12 @@ int ssd_render_full(ssd_env *env, int32_t e, uint8_t *rgb) {
 int ssd_set_horizon(ssd_env *env, int32_t horizon) {
     if (!env || horizon < 0) return SSD_E_INVALID;
     env->p.horizon = horizon;
+    return SSD_OK;
+}
+
+int ssd_set_rollout_chains(ssd_env *env, int32_t chains) {
+    if (!env || chains < 0 || chains > 8) return SSD_E_INVALID;
+    env->rollout_chains = chains;
     return SSD_OK;
 }
 

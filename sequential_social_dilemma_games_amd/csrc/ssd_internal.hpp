@@ -21,7 +21,8 @@ enum Stream : uint32_t {
 
 struct Params {
     // dimensions
-    int32_t E, N, H, W;
+    int32_t E, N, H, W;            // E: one past the last env this launch covers (the handle's env count unless a sub-range is launched)
+    int32_t e_begin;               // first env this launch covers (0 unless ssd_rollout_random splits the batch into chains)
     int32_t WP, S;                 // grid layout: row stride WP = W + view_len (row padding = '0'), S = H*WP rounded up to 16
                                    // (per-env stride of the grids in HBM); cell index = row * WP + col everywhere
     int32_t A0, A1;                // LDS aprons of the world layer (bytes, multiples of 16): view_len rows of '0' above / below

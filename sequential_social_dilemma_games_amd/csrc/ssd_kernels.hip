@@ -178,7 +178,7 @@ __host__ size_t lds_bytes(const Params &p, int envs_per_block, bool f32) {
 // round with at most one block per CU (256 CUs), small blocks once CUs run several rounds, and never fewer than
 // 256 blocks when the batch is small.  SSD_ENVS_PER_BLOCK overrides (tuning).
 __host__ int envs_per_block(const Params &p, bool f32) {
-    const int E = p.E;
+    const int E = p.E - p.e_begin;
     static const int forced = [] { const char *v = getenv("SSD_ENVS_PER_BLOCK"); return v ? atoi(v) : 0; }();
     auto pow2floor = [](int x) { int p = 1; while (p * 2 <= x) p *= 2; return p; };
     int fill = pow2floor(E / 256 > 0 ? E / 256 : 1);            // keep >= 256 blocks
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
     // needs one.  Pin what the prologue needs into SGPRs here so that the loads go out as one batch.
     asm volatile("" ::"s"(p.hdr), "s"(p.agents), "s"(p.world), "s"(p.lut), "s"(p.apple_cells), "s"(p.obs),
                  "s"(p.actions), "s"(p.order), "s"(p.n_apple), "s"(p.num_actions_random));
-    const int e = blockIdx.x * (int)(blockDim.x >> 6) + wv;
+    const int e = p.e_begin + blockIdx.x * (int)(blockDim.x >> 6) + wv;
     constexpr int mode = MODE;                               // compile-time: step / reset / observe
     bool active = e < p.E;                                   // wave-uniform
     if (active && mode == kModeReset && p.mask) active = p.mask[e] != 0;
@@ -1029,7 +1029,7 @@ static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipS
 void launch(const Params &p, int game, void *stream) {
     const bool f32 = p.obs && p.obs_f32;            // the float32-observation variant is a separate instantiation
     const int epb = envs_per_block(p, f32);
-    const dim3 grid((p.E + epb - 1) / epb), block(64 * epb);
+    const dim3 grid((p.E - p.e_begin + epb - 1) / epb), block(64 * epb);
     const size_t lds = lds_bytes(p, epb, f32);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (game == 0) { if (f32) launch_game<0, true>(p, grid, block, lds, s); else launch_game<0, false>(p, grid, block, lds, s); }

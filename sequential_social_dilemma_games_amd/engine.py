@@ -150,6 +150,10 @@ class VecEngine(object):
             _capi.check(rc, self._h)
         return obs, rew, done
 
+    def set_rollout_chains(self, chains):
+        """How many independent env ranges rollout_random() enqueues on streams of its own (0 = automatic)."""
+        _capi.check(self._L.ssd_set_rollout_chains(self._h, int(chains)), self._h)
+
     def rollout_random(self, n_steps, obs, rew=None, done=None, reset_every=0, step0=0, num_actions=None):
         """rollout.py:58-70 as ONE library call: `n_steps` random-action steps (plus a full reset whenever
         (step0 + k) % reset_every == 0) enqueued back to back.  obs / rew / done are device tensors with a leading ring

@@ -395,6 +395,7 @@ def test_rollout_random_is_the_same_launches_as_step_by_step(game):
         _, o_obs, o_rew, _ = ora.step_random()
         want[k] = (o_obs, o_rew)
     eng.rollout_random(10, obs, rew, done, reset_every=every, step0=0)
+    eng.set_rollout_chains(3)                                   # three env ranges on streams of their own: same results
     eng.rollout_random(13, obs, rew, done, reset_every=every, step0=10)
     got_obs, got_rew = obs.cpu().numpy(), rew.cpu().numpy()
     for k in range(23 - ring, 23):                              # the last `ring` steps are still in the ring

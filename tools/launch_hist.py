@@ -10,7 +10,7 @@ import numpy as np
 rows = list(csv.DictReader(open(sys.argv[1])))
 by = {}
 for r in rows:
-    by.setdefault(r["Kernel_Name"][:60], []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    by.setdefault(r["Kernel_Name"][:60] + " queue " + r.get("Queue_Id", "?"), []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 for name, v in by.items():
     if len(v) < 100:
         continue
@@ -25,3 +25,19 @@ for name, v in by.items():
     print("  duration us  pct %s: %s" % (q, np.percentile(d, q).round(2).tolist()))
     print("  gap us       pct %s: %s" % (q, np.percentile(gap, q).round(2).tolist()))
     print("  start pitch  pct %s: %s  mean %.2f" % (q, np.percentile(pitch, q).round(2).tolist(), pitch.mean()))
+
+# overlap between queues: fraction of time with 0 / 1 / 2+ step kernels in flight
+ev = []
+for name, v in by.items():
+    if "ssd_env_kernel" in name and len(v) >= 100:
+        for a, b in v[len(v) // 4: -len(v) // 4]:
+            ev.append((a, 1)); ev.append((b, -1))
+ev.sort()
+if ev:
+    busy = {}
+    cur, last = 0, ev[0][0]
+    for t, d in ev:
+        busy[cur] = busy.get(cur, 0) + (t - last)
+        cur += d; last = t
+    tot = sum(busy.values())
+    print("step kernels in flight (middle half of the run): " + ", ".join("%d: %.1f %%" % (k, 100.0 * v / tot) for k, v in sorted(busy.items())))
