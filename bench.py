@@ -150,10 +150,27 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)
     if eng.status() != 0:
         raise SystemExit("device status word is non-zero")
+    # Reported separately and labelled: the same K steps as ONE fused kernel launch -- every env
+    # resident in LDS / registers across its steps (SSD_ROLLOUT_FUSED).  Not part of `value`.
+    fused_ms = None
+    if use_rollout and not args.obs_f32:
+        eng.rollout_random(args.warmup, ring[0], ring[1], ring[2], reset_every=HORIZON, step0=0, fused=True)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record()
+        eng.rollout_random(args.steps, ring[0], ring[1], ring[2], reset_every=HORIZON, step0=args.warmup, fused=True)
+        f1.record()
+        torch.cuda.synchronize()
+        fused_ms = f0.elapsed_time(f1)
+        if eng.status() != 0:
+            raise SystemExit("device status word is non-zero")
     if dist is not None:
-        tw = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+        tw = torch.tensor([wall, dev_ms, fused_ms or 0.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(tw[0]), float(tw[1])
+        fused_ms = float(tw[2]) if fused_ms is not None else None
 
     if rank == 0:
         total_agent_steps = float(E) * n_agents * args.steps * world
@@ -176,6 +193,13 @@ def main():
                          "kernel": "ssd::ssd_env_kernel<%d, 0, %s, ...>" % (game, "true" if args.obs_f32 else "false"), "bytes_per_env_step": bytes_env,
                          "avg_launch_us": launch_us, "concurrent_launches": chains, "host_enqueue_us_per_step": enq * 1e6 / args.steps},
         }
+        if fused_ms is not None:
+            fus = fused_ms * 1e3 / args.steps
+            res["fused_rollout"] = {
+                "label": "NOT the headline: the same %d steps as ONE kernel launch per GPU (ssd_rollout_random + SSD_ROLLOUT_FUSED), "
+                         "envs resident in LDS across steps; per-step obs / rew / done still written to HBM" % args.steps,
+                "value": total_agent_steps / (fused_ms * 1e-3), "unit": "agent-env-steps/s", "us_per_step": fus,
+                "roofline_frac": bytes_env * E / (fus * 1e-6) / 1e9 / HBM_PEAK_GBS}
         # HBM bytes per launch from the PMC counters of the committed profile of this exact workload
         # (tools/profile_gpu.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE correction)
         tpath = os.path.join(REPO, "profiles", "r01_traffic.json")

@@ -52,6 +52,9 @@ enum {
                                 they are device pointers on the handle's device and the call only
                                 enqueues work on `stream`. */
     SSD_NO_ROTATE = 1u << 1, /* ssd_observe only: reset-form observation (map_env.py:239-240) */
+    SSD_ROLLOUT_FUSED = 1u << 3, /* ssd_rollout_random only: ONE kernel launch for the whole call -- every env stays in LDS and
+                                registers across its n_steps steps and only the per-step outputs (and, at the end, the state)
+                                go to HBM.  Same results; no per-step launch, state reload or write-back.  uint8 obs only. */
     SSD_OBS_F32 = 1u << 2    /* obs points at float32 [E,N,V,V,3] instead of uint8: the normalisation of map_env.py:199
                                 fused into the kernel (4x the observation bytes; a separate, slower mode) */
 };

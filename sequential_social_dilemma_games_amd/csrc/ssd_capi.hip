@@ -258,7 +258,7 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
     }
 
     Params &p = env->p;
-    p.E = E; p.N = N; p.H = H; p.W = W; p.WP = WP; p.S = S;
+    p.E = E; p.E_total = E; p.ring = 1; p.N = N; p.H = H; p.W = W; p.WP = WP; p.S = S;
     p.A0 = (cfg->view_len * (WP + 1) + 15) & ~15;
     p.A1 = (cfg->view_len * WP + 15) & ~15;
     p.view_len = cfg->view_len; p.V = V; p.beam_len = cfg->beam_len;
@@ -367,6 +367,15 @@ static int rollout_chain(ssd_env *env, int e_begin, int e_end, int32_t num_actio
     Params p = env->p;
     p.obs_f32 = f32 ? 1 : 0;
     p.e_begin = e_begin; p.E = e_end;
+    if (flags & SSD_ROLLOUT_FUSED) {
+        // ONE launch for the whole chain: the kernel keeps each env in LDS / registers across its n_steps steps
+        if (n_steps == 0) return SSD_OK;
+        p.mode = ssd::kModeRollout; p.rotate = 1; p.num_actions_random = num_actions;
+        p.n_steps = n_steps; p.reset_every = reset_every; p.step0 = step0; p.ring = ring;
+        p.obs = obs; p.rew = rew; p.done = done;
+        ssd::launch(p, env->game, s);
+        return hipGetLastError() == hipSuccess ? SSD_OK : SSD_E_DEVICE;
+    }
     for (int k = 0; k < n_steps; ++k) {
         const size_t slot = (size_t)((step0 + k) % ring);
         p.obs = obs ? obs + slot * ob : nullptr;
@@ -388,6 +397,7 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
     const int na = env->game == SSD_GAME_HARVEST ? 8 : 9;
     if (num_actions < 1 || num_actions > na) { env->err = "num_actions outside the game's Discrete(n)"; return SSD_E_INVALID; }
     if (obs && (reinterpret_cast<uintptr_t>(obs) & 3u)) { env->err = "obs must be 4-byte aligned"; return SSD_E_INVALID; }
+    if ((flags & SSD_ROLLOUT_FUSED) && (flags & SSD_OBS_F32)) { env->err = "the fused rollout kernel writes uint8 observations"; return SSD_E_INVALID; }
     SSD_HIP(env, hipSetDevice(env->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     uint8_t *o = static_cast<uint8_t *>(obs);
@@ -396,6 +406,7 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
     // dispatched -- the ~2 us per launch that a single chain of 9 us kernels cannot hide.  SSD_ROLLOUT_CHAINS overrides.
     static const int forced = [] { const char *v = getenv("SSD_ROLLOUT_CHAINS"); return v ? atoi(v) : 0; }();
     int chains = env->rollout_chains > 0 ? env->rollout_chains : forced > 0 ? forced : (env->E >= 2048 && n_steps >= 16 ? 2 : 1);
+    if ((flags & SSD_ROLLOUT_FUSED) && env->rollout_chains <= 0 && forced <= 0) chains = 1;   // one launch already covers the whole rollout
     if (chains > 8) chains = 8;
     if (chains > env->E) chains = env->E;
     if (chains <= 1) {

@@ -12,7 +12,7 @@ constexpr int kMaxBeamLen = 21;    // 3 rays * beam_len lanes must fit one wavef
 
 constexpr int kListRegs = 3;       // per-lane registers holding the first 192 entries of a static cell list
 
-enum Mode : int32_t { kModeStep = 0, kModeReset = 1, kModeObserve = 2 };
+enum Mode : int32_t { kModeStep = 0, kModeReset = 1, kModeObserve = 2, kModeRollout = 3 };   // rollout: n_steps random-action steps in ONE launch
 
 // PRNG streams (sequential_social_dilemma_games_amd/prng.py)
 enum Stream : uint32_t {
@@ -29,6 +29,8 @@ struct Params {
     int32_t view_len, V, beam_len;
     int32_t mode, rotate, keep_beams, num_actions_random;
     int32_t obs_f32;               // obs is float32 [E,N,V,V,3] (SSD_OBS_F32) instead of uint8
+    int32_t n_steps, reset_every, step0, ring, E_total;   // kModeRollout: steps in this launch, reset period (0 = never), index of the
+                                   // first step, slots in the output ring, env count of the handle (slot stride)
     int32_t horizon;               // > 0: done = (t >= horizon), RLlib's `horizon` (train_baseline.py:131); 0: never done
     uint32_t v_magic16;            // ceil(2^16 / V): pp / V == (pp * v_magic16) >> 16 for pp < V*V, V <= 31
     uint32_t seed_lo, seed_hi, env_base;

@@ -168,8 +168,11 @@ __device__ __forceinline__ uint32_t count_bytes_eq(uint32_t x, uint32_t ch) {
 // utility_funcs.py:94-114 adds around the map -- is then plain memory around the agent's cell: the
 // observation phase needs no bounds test and no row / column arithmetic at all.
 // ---------------------------------------------------------------------------------------------
+// The rollout kernel (kModeRollout) keeps the env in LDS across steps, so its overlay goes to a fourth layer (`view`,
+// which then carries the aprons) instead of overwriting the world layer in place.
 __host__ size_t lds_bytes(const Params &p, int envs_per_block, bool f32) {
-    return (size_t)envs_per_block * (128 * 4 + 256 + (f32 ? 256 * 4 : 0) + (size_t)p.A0 + (size_t)p.A1 + 3 * (size_t)p.S);
+    const int layers = p.mode == kModeRollout ? 4 : 3;
+    return (size_t)envs_per_block * (128 * 4 + 256 + (f32 ? 256 * 4 : 0) + (size_t)p.A0 + (size_t)p.A1 + layers * (size_t)p.S);
 }
 
 // Envs (= waves) per workgroup.  Waves are independent, so this only changes dispatch granularity; measured on
@@ -212,12 +215,15 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
     const int A0 = FAST ? (GAME == 0 ? 336 : 192) : p.A0, A1 = FAST ? (GAME == 0 ? 320 : 176) : p.A1;
     const int N = NA > 0 ? NA : p.N;
     const bool has_order = !FAST && p.order != nullptr, keep_beams = !FAST && p.keep_beams != 0;
-    uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + (size_t)wv * (512 + 256 + (F32 ? 1024 : 0) + (size_t)A0 + (size_t)A1 + 3 * (size_t)S));
+    constexpr bool roll = MODE == kModeRollout;                     // many steps per launch, env resident in LDS
+    uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + (size_t)wv * (512 + 256 + (F32 ? 1024 : 0) + (size_t)A0 + (size_t)A1 +
+                                                                            (roll ? 4 : 3) * (size_t)S));
     uint32_t *s_tmp = s_lut + 128;                                  // 64 list entries of scratch (respawn compaction)
     float *s_f32 = reinterpret_cast<float *>(s_lut + 192);          // float32-observation kernels only
-    uint8_t *s_world = reinterpret_cast<uint8_t *>(s_lut + 192 + (F32 ? 256 : 0)) + A0;
-    uint8_t *s_beam = s_world + S + A1;
+    uint8_t *s_world = reinterpret_cast<uint8_t *>(s_lut + 192 + (F32 ? 256 : 0)) + (roll ? 0 : A0);
+    uint8_t *s_beam = s_world + S + (roll ? 0 : A1);
     uint8_t *s_occ = s_beam + S;
+    uint8_t *s_view = roll ? s_occ + S + A0 : s_world;              // what the observations read: world <- agents <- beams
 
     // Kernel arguments are fetched lazily by default, one scalar-cache round trip per basic block that
     // needs one.  Pin what the prologue needs into SGPRs here so that the loads go out as one batch.
@@ -276,11 +282,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
             *reinterpret_cast<uint4 *>(s_beam + lane * 16) = b0;
             *reinterpret_cast<uint4 *>(s_occ + lane * 16) = make_uint4(0, 0, 0, 0);
         }
-        if (p.obs) {                                         // the aprons of the world layer: '0' (void) cells
+        if (p.obs) {                                         // the aprons of the layer the observations read: '0' (void) cells
             const uint4 z = make_uint4(0x30303030u, 0x30303030u, 0x30303030u, 0x30303030u);
             const int n0 = A0 >> 4, n1 = A1 >> 4;
             for (int i = lane; i < n0 + n1; i += 64)
-                *reinterpret_cast<uint4 *>(i < n0 ? s_world - A0 + i * 16 : s_world + S + (i - n0) * 16) = z;
+                *reinterpret_cast<uint4 *>(i < n0 ? s_view - A0 + i * 16 : s_view + S + (i - n0) * 16) = z;
         }
         for (int i = lane * 16 + 1024; i < S; i += 1024) {   // maps above 1024 cells
             uint4 bv = make_uint4(0, 0, 0, 0);
@@ -291,693 +297,736 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
         }
         wave_sync();
 
-        if (mode == kModeReset) {
-            // ---- MapEnv.reset (map_env.py:214-249) ----
-            episode += 1; t = 0;
-            key = env_key(p.seed_lo, p.seed_hi, p.env_base + (uint32_t)e, episode);
-            // the grid loaded above is reset_map (:560-564) + custom_reset of the base map
-            // setup_agents (harvest.py:46-55 / cleanup.py:118-130): spawn_point (map_env.py:651-662) takes
-            // the LAST free point of a fresh shuffle = the free point with the largest (draw, cell);
-            // spawn_rotation (:664-667) indexes [LEFT, RIGHT, UP, DOWN].
-            const uint32_t pk_pt = phase_key(key, 0, kSpawnPoint), pk_rot = phase_key(key, 0, kSpawnRot);
-            for (int i = 0; i < N; ++i) {
-                bool has = false;
-                uint32_t bh = 0, bl = 0;                     // lane-local min of (~draw, ~cell) = max of (draw, cell)
-                for (int s = lane; s < p.n_spawn; s += 64) {
-                    const uint32_t ce = p.spawn_cells[s], c = ce & 0xFFFFu;         // grid index | dense index << 16
-                    if (s_occ[c] == 0) {
-                        const uint32_t kh = ~draw(pk_pt, ((uint32_t)i << 16) | (ce >> 16)), kl = ~c;
-                        if (!has || kh < bh || (kh == bh && kl < bl)) { bh = kh; bl = kl; has = true; }
-                    }
-                }
-                uint32_t oh, ol, chosen;
-                if (wave_argmin_pair(has, bh, bl, oh, ol)) chosen = ~ol;
-                else { status |= kStNoSpawn; chosen = p.n_spawn ? (p.spawn_cells[0] & 0xFFFFu) : (uint32_t)(WP + 1); }
-                if (lane == i) { cell = chosen; orient = randint(draw(pk_rot, (uint32_t)i), 4); }
-                s_occ[chosen] = agent_glyph((uint32_t)i);    // all lanes, same address, same value
-                wave_sync();
-            }
-        }
-
-        SSD_STAMP(1);   // state loaded
-        int act = -1;
-        uint32_t ordv = (uint32_t)lane;                      // action order list, lane k = k-th acting agent
-        int nord = N;
-        if (mode == kModeStep) {
-            t += 1;
-            // ---- actions (map_env.py:171-173) ----
-            if (p.num_actions_random > 0) {                  // rollout.py:64-65 uniform random actions
-                const uint32_t pk = phase_key(key, t, kAction);
-                if (is_agent) {
-                    act = (int)randint(draw(pk, (uint32_t)lane), (uint32_t)p.num_actions_random);
-                    if (p.actions_out) p.actions_out[(size_t)e * N + lane] = act;
-                }
-            } else {
-                act = act_in;
-            }
-            constexpr int kNumActions = GAME == 0 ? 8 : 9;   // harvest.py:44, cleanup.py:70
-            const bool bad = is_agent && (act < -1 || act >= kNumActions);
-            if (ballot(bad)) { status |= kStBadAction; if (bad) act = -1; }
-            if (has_order) {
-                ordv = ord_in;
-                if (ordv != 0xFFu && ordv >= (uint32_t)N) { ordv = 0xFFu; status |= kStBadAction; }
-                const uint64_t endm = ballot(ordv == 0xFFu);
-                nord = endm ? __builtin_ctzll(endm) : 64;
-                uint64_t acting = 0;
-                for (int k = 0; k < nord; ++k) acting |= bit(rl(ordv, k));
-                if (!((acting >> lane) & 1)) act = -1;       // agents absent from the action dict do nothing
-            }
-
-            // A launch lasts as long as its slowest wave.  How long a wave will take is known here: in Cleanup every
-            // beam costs ~0.5 us (they are traced one after the other), the conflict path of the moves ~1.5 us.  Waves
-            // with more work ahead issue ahead of the waves they share a SIMD with (which have slack); measured
-            // -0.5 us per 4096-env launch.  (Harvest traces all beams at once: no priority needed for them.)
-            if (GAME == 1) {
-                constexpr int kFireAct = 7, kCleanAct = 8;
-                const int ns = __builtin_popcountll(ballot(is_agent && (act == kFireAct || act == kCleanAct)));
-                if (ns >= 2) __builtin_amdgcn_s_setprio(2);
-                else if (ns == 1) __builtin_amdgcn_s_setprio(1);
-            }
-            // ---- update_moves (map_env.py:357-543) ----
-            const bool mover = !SSD_SKIP(0) && is_agent && act >= 0 && act <= 4;              // :383
-            if (is_agent && (act == 5 || act == 6)) orient = turn(act, orient);   // :390-392
-            uint32_t tcell = cell;
-            {   // every lane runs this (non-movers get a zero step), so the wall read is one unconditional LDS load.
-                // MOVE_* vectors (map_env.py:11-15) and rotate_action (:701-716: UP v, LEFT (vc,-vr), RIGHT (-vc,vr),
-                // DOWN -v) as arithmetic on a cyclic direction index (0 (-1,0), 1 (0,1), 2 (1,0), 3 (0,-1)): the
-                // move code picks an index, the orientation adds a quarter-turn count.  Tables are 5-bit fields
-                // holding 8 * index, so the sum (mod 32, which the bit-field extract applies by itself) is the
-                // bit offset of the result's byte.
-                constexpr uint32_t kMoveIdx8 = (0u << 0) | (16u << 5) | (24u << 10) | (8u << 15);   // MOVE_* codes 0..3
-                constexpr uint32_t kTurns8 = (8u << 0) | (24u << 5) | (0u << 10) | (16u << 15);     // LEFT, RIGHT, UP, DOWN
-                const uint32_t sum = __builtin_amdgcn_ubfe(kMoveIdx8, (uint32_t)act * 5u, 5u) + __builtin_amdgcn_ubfe(kTurns8, orient * 5u, 5u);
-                int step;
-                if (FAST) {                                  // row stride fits a signed byte: the table holds the cell offsets
-                    const uint32_t off4 = ((uint32_t)(-WP) & 0xFFu) | (1u << 8) | ((uint32_t)WP << 16) | (0xFFu << 24);
-                    step = __builtin_amdgcn_sbfe(off4, sum, 8u);
-                } else {
-                    step = __builtin_amdgcn_sbfe(0x000100FFu, sum, 8u) * WP + __builtin_amdgcn_sbfe(0xFF000100u, sum, 8u);
-                }
-                const uint32_t cand = (uint32_t)((int)cell + ((mover & (act < 4)) ? step : 0));    // STAY (4) is a zero step
-                // agent.py:105-113 return_valid_pos (the agent's grid agrees with world_map on '@')
-                tcell = (mover & (s_world[cand] != '@')) ? cand : cell;
-            }
-            uint32_t mvcell = tcell;                         // agent_moves[id] (:410)
-            const uint64_t M = ballot(mover);
-            // Fast path.  If no mover's target is a cell some OTHER agent stands on and no two movers
-            // share a target, every branch of :424-543 degenerates to "each mover takes its target"
-            // whatever the shuffle says (STAY / wall-blocked movers target their own cell and stay), and
-            // since draws are counter-keyed there is no RNG state to advance.  Otherwise run the
-            // reference algorithm in full.
-            const uint64_t agents_m = N >= 64 ? ~0ull : bit((uint32_t)N) - 1;
-            uint64_t clashm = 0, dupm = 0;                   // lanes (!= j) whose target is agent j's cell or mover j's target
-            for (int j = 0; j < N; ++j) {
-                const uint32_t cj = rl(cell, j), tj = rl(tcell, j);
-                const uint64_t on_cell = ballot(tcell == cj), on_target = (((M >> j) & 1) ? ballot(tcell == tj) : 0ull) & ~bit(j);
-                clashm |= (on_cell & ~bit(j)) | on_target;
-                dupm |= on_target;
-            }
-            const bool slow = (clashm & M) != 0;
-            SSD_NOTE(12, slow ? 1 : 0);
-            if (!slow) {
-                if (mover) cell = tcell;
-            } else {                                         // :415 (M != 0 here)
-                __builtin_amdgcn_s_setprio(3);               // the slowest waves of a launch come through here (1-2 % of the envs)
-                uint64_t Hm = M;                             // ids that still have an entry in agent_moves
-                // :424-491 cells wanted by several agents, in lexicographic order (np.unique, axis=0): visited in
-                // ascending cell order (scalar min over the few lanes involved).  The shuffle of :421-423 only
-                // decides who wins such a cell, so it is only computed when there is one (draws are counter-keyed).
-                uint64_t todo = dupm & M;
-                if (todo) {
-                    const int nm = __builtin_popcountll(M);
-                    uint32_t perm = 0;                       // lane k: k-th entry of the (shuffled) zipped list
-                    {
-                        int cnt = 0;
-                        for (int k = 0; k < nord; ++k) {
-                            const uint32_t a = has_order ? rl(ordv, k) : (uint32_t)k;
-                            if ((M >> a) & 1) { if (lane == cnt) perm = a; ++cnt; }
-                        }
-                    }
-                    const uint32_t pk = phase_key(key, t, kMove);
-                    for (int i = nm - 1; i >= 1; --i) {      // :421-423 np.random.shuffle = Fisher-Yates from the end
-                        const uint32_t j = randint(draw(pk, (uint32_t)i), (uint32_t)i + 1);
-                        const uint32_t vi = rl(perm, i), vj = rl(perm, j);
-                        if (lane == i) perm = vj;
-                        if (lane == (int)j) perm = vi;
-                    }
-                    while (todo) {
-                        uint32_t nxt = 0xFFFFFFFFu;
-                        for (uint64_t m = todo; m; m &= m - 1) nxt = umin(nxt, rl(tcell, __builtin_ctzll(m)));
-                        const uint64_t Cm = ballot(mover && tcell == nxt);          // contenders (:441-442)
-                        todo &= ~Cm;
-                        bool cell_free = true;
-                        const uint64_t Pm = ballot(is_agent && cell == nxt);        // :449 move in self.agent_pos
-                        if (Pm) {
-                            const uint32_t occ = 63 - __builtin_clzll(Pm);          // agent_by_pos: last index wins
-                            const uint32_t occ_mv = rl(mvcell, occ);
-                            if ((Cm >> occ) & 1) cell_free = false;                 // (1) :460
-                            else if (!((Hm >> occ) & 1) || occ_mv == nxt) cell_free = false;    // (2) :466-468
-                            else if (ballot(__builtin_amdgcn_inverse_ballot_w64(Cm) && cell == occ_mv)) cell_free = false; // (3) :472-476
-                        }
-                        if (cell_free) {                     // :480-483 first contender in shuffled order moves NOW
-                            uint32_t w = 0;
-                            for (int k = 0; k < nm; ++k) { w = rl(perm, k); if ((Cm >> w) & 1) break; }
-                            if (lane == (int)w) cell = nxt;
-                        }
-                        if (__builtin_amdgcn_inverse_ballot_w64(Cm)) mvcell = cell;   // :486-491 every contender's move becomes "stay"
-                    }
-                }
-                // :494-543 remaining moves: chains, swaps, cycles.  Who stands on each agent's target, and does any cell
-                // hold two agents (possible after a contested cell was entered while its occupant was still there)?
-                uint64_t overlap = 0;
-                int occ_of_target = -1;
-                for (int j = 0; j < N; ++j) {
-                    const uint32_t cj = rl(cell, j);
-                    occ_of_target = (mvcell == cj) ? j : occ_of_target;
-                    overlap |= ballot(cell == cj) & agents_m & ~bit(j);
-                }
-                if (!overlap) {
-                    // Usual case: every cell holds at most one agent and (after the step above) no two pending moves
-                    // share a target, so "a waits for the agent on its target" is a graph of disjoint paths and cycles,
-                    // and the pass loop of :494-543 comes out as: a path moves as a whole iff its head's target is free;
-                    // it stays as a whole if it ends at an agent that is not moving; a 2-cycle (swap, :524-530) stays;
-                    // longer cycles rotate (:540-543).  Resolved by pointer jumping over lanes, ceil(log2 N) rounds.
-                    const bool pend = __builtin_amdgcn_inverse_ballot_w64(Hm) & (mvcell != cell);
-                    int st = pend ? (occ_of_target < 0 ? 1 : 2) : 0;                // 0 stays, 1 moves, 2 waits for lane `nx`
-                    const int nx0 = (occ_of_target & 63) << 2;
-                    int nx = nx0;
-                    for (int r = 1; r < N; r <<= 1) {
-                        const int s2 = __builtin_amdgcn_ds_bpermute(nx, st), n2 = __builtin_amdgcn_ds_bpermute(nx, nx);
-                        const bool waiting = st == 2;
-                        st = (waiting & (s2 != 2)) ? s2 : st;
-                        nx = (waiting & (s2 == 2)) ? n2 : nx;
-                    }
-                    if (ballot(st == 2)) {                                          // still waiting: on a cycle
-                        const int back = __builtin_amdgcn_ds_bpermute(nx0, nx0);    // my target's target ...
-                        st = st == 2 ? (back == (lane << 2) ? 0 : 1) : st;          // ... is me: a swap
-                    }
-                    if (st == 1) cell = mvcell;
-                } else
-                while (Hm) {
-                    const uint32_t snap_cell = cell, snap_mv = mvcell;              // agent_by_pos (:495), moves_copy (:498)
-                    const uint64_t snapH = Hm;
-                    uint64_t del = 0;
-                    const int n0 = __builtin_popcountll(Hm);
-                    for (int k = 0; k < nord; ++k) {                                // agent_moves insertion order = action order
-                        const uint32_t a = has_order ? rl(ordv, k) : (uint32_t)k;
-                        if (!((snapH >> a) & 1) || ((del >> a) & 1)) continue;      // :500-502
-                        const uint32_t m = rl(snap_mv, a);
-                        if (ballot(is_agent && cell == m)) {                        // :503 (live positions)
-                            const uint64_t sm = ballot(is_agent && snap_cell == m); // :506 (pass-start snapshot)
-                            if (!sm) { status |= kStMoveLookup; Hm &= ~bit(a); del |= bit(a); continue; }
-                            const uint32_t occ = 63 - __builtin_clzll(sm);
-                            const uint32_t ccp = rl(cell, occ), occ_mv = rl(mvcell, occ);
-                            const uint32_t cm = ((Hm >> occ) & 1) ? occ_mv : ccp;   // :509
-                            const uint32_t pa = rl(cell, a);
-                            if (a == occ) { Hm &= ~bit(a); del |= bit(a); }         // (1) :512-514
-                            else if (!((snapH >> occ) & 1) || ccp == cm) { Hm &= ~bit(a); del |= bit(a); }  // (2) :518-521
-                            else if (occ_mv == pa && m == ccp) {                    // (3) :524-530 swap: both give up
-                                Hm &= ~(bit(a) | bit(occ)); del |= bit(a) | bit(occ);
-                            }
-                        } else {                                                    // :532-535
-                            if (lane == (int)a) cell = m;
-                            Hm &= ~bit(a); del |= bit(a);
-                        }
-                    }
-                    if (__builtin_popcountll(Hm) == n0) {    // :540-543 only cycles are left: rotate them
-                        if (__builtin_amdgcn_inverse_ballot_w64(Hm)) cell = mvcell;
-                        break;
-                    }
-                }
-            }
-        }
-
-        SSD_STAMP(2);   // moves resolved
-        uint64_t highest = 0;                                // agents that are the highest index on their cell (agent_by_pos, :603)
-        if (mode != kModeReset && !SSD_SKIP(1)) {
-            // ---- consume (map_env.py:178-181, agent.py:177-183) + occupancy layer ----
-            // Index order means: of several agents on one cell the LOWEST index eats the apple, and
-            // agent_by_pos / the overlay show the HIGHEST index (:289-297, :603).
-            // Wave masks on the scalar unit: agent j is the lowest (highest) index on its cell iff no lower (higher)
-            // bit is set among the agents standing where it stands.
-            const uint64_t agents = N >= 64 ? ~0ull : bit((uint32_t)N) - 1;
-            uint64_t lowest = 0;
-            for (int j = 0; j < N; ++j) {
-                const uint64_t here = ballot(cell == rl(cell, j)) & agents;
-                lowest |= (here & (bit(j) - 1)) ? 0ull : bit(j);
-                highest |= ((here >> j) >> 1) ? 0ull : bit(j);
-            }
-            const bool eats = (mode == kModeStep) & __builtin_amdgcn_inverse_ballot_w64(lowest) & (s_world[cell] == 'A');
-            if (eats) { s_world[cell] = ' '; rew += 1; }
-            if (__builtin_amdgcn_inverse_ballot_w64(highest)) s_occ[cell] = agent_glyph((uint32_t)lane);
-            wave_sync();
-        }
-
-        SSD_STAMP(3);   // consume + occupancy
-        if (mode == kModeStep) {
-            // ---- update_custom_moves (map_env.py:545-552): beams in action order ----
-            const int L = STD ? 5 : p.beam_len;
-            const uint32_t rmask = (1u << L) - 1u;
-            constexpr int kFire = 7, kClean = 8;
-            uint64_t shooters = SSD_SKIP(2) ? 0ull : ballot(is_agent && (act == kFire || (GAME == 1 && act == kClean)));
-            SSD_NOTE(13, __builtin_popcountll(shooters));
-            if (GAME == 0 && shooters) {
-                // Harvest: a FIRE beam changes nothing another beam reads (no cell types, no blocking cells, harvest.py:62-67;
-                // 'F' marks and penalties commute), so the rays of up to 64 / 3L shooters are traced in ONE pass:
-                // lane = (shooter slot g, ray q, step kk).  A wave with three shooters costs what one shooter costs.
-                const int R = 3 * L, G = STD ? 4 : 64 / R;
-                const int g = STD ? lane / 15 : lane / R, r = lane - g * R;
-                const int q = (r >= L) + (r >= 2 * L), kk = r - q * L;
-                const int cq = q == 1 ? 1 : q == 2 ? -1 : 0, ck = kk + (q == 0);   // ray cell = pos + cq * right + ck * d (:608-609)
-                const int sh = g * R + q * L;                                       // first lane of this lane's ray
-                if (is_agent && act == kFire) rew -= 1;                             // agent.py:170-172 fire_beam('F')
-                const uint32_t packed_agent = cell | (orient << 16);
-                while (shooters) {
-                    int a = -1, taken = 0;                                          // slot g <- the g-th remaining shooter
-                    for (; taken < G && shooters; ++taken) {
-                        const int b = __builtin_ctzll(shooters);
-                        a = (g == taken) ? b : a;
-                        shooters &= shooters - 1;
-                    }
-                    const bool inray = a >= 0;
-                    const uint32_t ar = (uint32_t)__builtin_amdgcn_ds_bpermute((inray ? a : 0) << 2, (int)packed_agent);
-                    const int pc = (int)(ar & 0xFFFFu);
-                    const uint32_t o8 = (ar >> 16) << 3;                            // orientation code * 8: LEFT RIGHT UP DOWN
-                    int dlin, rlin;                                                 // d and rotate_right(d) = (-dc, dr) (:607) as cell offsets
-                    if (FAST) {
-                        const uint32_t b = (uint32_t)WP & 0xFFu, nb = (uint32_t)(-WP) & 0xFFu;
-                        dlin = __builtin_amdgcn_sbfe(nb | (b << 8) | (0xFFu << 16) | (1u << 24), o8, 8u);   // -WP, WP, -1, 1
-                        rlin = __builtin_amdgcn_sbfe(0xFFu | (1u << 8) | (b << 16) | (nb << 24), o8, 8u);   // -1, 1, WP, -WP
-                    } else {
-                        const int dr = __builtin_amdgcn_sbfe(0x000001FFu, o8, 8u), dc = __builtin_amdgcn_sbfe(0x01FF0000u, o8, 8u);
-                        dlin = dr * WP + dc; rlin = -dc * WP + dr;
-                    }
-                    // The map's border is wall and a ray ends at the first '@' (:616), so the in-bounds test of :615 can
-                    // never be what stops it: cells past the wall are read (harmlessly) and ignored by the first-stop logic.
-                    const int cidx = inray ? pc + __mul24(rlin, cq) + __mul24(dlin, ck) : WP + 1;
-                    const uint8_t wch = s_world[cidx], och = s_occ[cidx];
-                    const bool pass = inray & (wch != '@');                         // :616
-                    const bool stopper = pass & (och != 0);                         // :621 agents absorb the beam
-                    const uint64_t mf = ballot(inray & !pass), ms = ballot(stopper);
-                    const uint32_t f = (uint32_t)(mf >> sh) & rmask, st = (uint32_t)(ms >> sh) & rmask;
-                    const int ff = f ? __builtin_ctz(f) : L, fs = st ? __builtin_ctz(st) : L;
-                    const int len = fs < ff ? fs + 1 : ff;                          // beam covers the stopping cell
-                    if (inray && kk < len) s_beam[cidx] = 'F';                      // :624 firing_points (nothing reads the beam layer here)
-                    // agent.py:166-168 hit('F'): the last-index agent (:603) on a cell where a ray stopped loses 50 per ray
-                    uint64_t hits = ballot(stopper & (kk == fs) & (fs < ff));
-                    const bool top = __builtin_amdgcn_inverse_ballot_w64(highest);
-                    for (; hits; hits &= hits - 1) {
-                        const uint32_t hit_cell = rl((uint32_t)cidx, (uint32_t)__builtin_ctzll(hits));
-                        rew -= (top & (cell == hit_cell)) ? 50 : 0;
-                    }
-                }
-                wave_sync();
-            }
-            for (int k = 0; GAME == 1 && shooters && k < nord; ++k) {
-                const uint32_t a = rl(ordv, k);
-                if (!((shooters >> a) & 1)) continue;
-                shooters &= ~bit(a);
-                const int aa = (int)rl((uint32_t)act, a);
-                const bool fire = aa == kFire, clean = !fire;                       // harvest.py:62-67, cleanup.py:94-111
-                if (fire && lane == (int)a) rew -= 1;                               // agent.py:170-172 fire_beam('F')
-                // update_map_fire (map_env.py:566-649): lane = (ray q, step kk)
-                const int pc = (int)rl(cell, a);
-                int dr, dc;
-                unit_vec((int)rl(orient, a), dr, dc);
-                const int dlin = dr * WP + dc, rlin = -dc * WP + dr;                // d and rotate_right(d) = (-dc, dr) (:607) as cell offsets
-                const int q = (lane >= L) + (lane >= 2 * L), kk = lane - q * L;
-                const bool inray = lane < 3 * L;
-                // :608-609 rays start at pos, pos + right - d, pos - right - d; ray cell kk is start + (kk + 1) * d.
-                // The map's border is wall (ssd_create / ssd_set_state insist) and a ray ends at the first '@'
-                // (:616), so the in-bounds test of :615 can never be what stops it: cells past the wall are
-                // read (harmlessly, possibly outside the grid) and ignored by the first-stop logic below.
-                const int cidx = inray ? pc + (q == 1 ? rlin : q == 2 ? -rlin : 0) + dlin * (kk + (q == 0)) : pc;
-                const uint8_t wch = s_world[cidx], och = s_occ[cidx];
-                const bool pass = inray & (wch != '@');                             // :616
-                const bool stopper = pass & ((och != 0) | (clean & (wch == 'H')));  // :621 agents absorb, :639 blocking cell
-                const uint64_t mf = ballot(inray & !pass), ms = ballot(stopper);
-                const uint32_t f = (uint32_t)(mf >> (q * L)) & rmask, s = (uint32_t)(ms >> (q * L)) & rmask;
-                const int ff = f ? __builtin_ctz(f) : L, fs = s ? __builtin_ctz(s) : L;
-                const int len = fs < ff ? fs + 1 : ff;                              // beam covers the stopping cell
-                wave_sync();
-                if (inray && kk < len) {
-                    s_beam[cidx] = clean ? 'C' : 'F';                               // :624,:636 firing_points
-                    if (clean && wch == 'H') s_world[cidx] = 'R';                   // :625-634 cell_types ['H'] -> ['R']
-                }
-                if (fire) {                                                         // agent.py:166-168 hit('F'): -50
-                    for (int q2 = 0; q2 < 3; ++q2) {
-                        const uint32_t f2 = (uint32_t)(mf >> (q2 * L)) & rmask, s2 = (uint32_t)(ms >> (q2 * L)) & rmask;
-                        const int ff2 = f2 ? __builtin_ctz(f2) : L, fs2 = s2 ? __builtin_ctz(s2) : L;
-                        if (fs2 < ff2) {
-                            const uint32_t sl = (uint32_t)(q2 * L + fs2);
-                            if (rl((uint32_t)och, sl)) {                            // an agent (not waste) stopped the ray
-                                const uint32_t hit_cell = rl((uint32_t)cidx, sl);
-                                const uint64_t vm = ballot(is_agent && cell == hit_cell);
-                                if (vm && lane == 63 - __builtin_clzll(vm)) rew -= 50;   // :603 last index wins
-                            }
-                        }
-                    }
-                }
-                wave_sync();                                                        // :551-552 updates land before the next shooter
-            }
-        }
-
-        SSD_STAMP(4);   // beams
-        if (mode != kModeObserve) {
-            // ---- custom_map_update (map_env.py:187 / :230): respawn ----
-            // Lanes walk the map's static apple-point list (row-major, as the reference iterates it).  A list entry is
-            // grid index | dense index << 16: the grid index addresses the padded-row layers, the dense index
-            // (row * W + col, what prng.py keys the per-cell draws with) feeds the PRNG.
-            // The LDS reads of one list entry are unconditional (padding entries point at an interior
-            // cell), so they go out as one independent batch.
-            uint64_t spawn_bits = 0;                                                // bit j: list entry lane + 64*j gets an apple
-            const uint32_t pk_apple = phase_key(key, t, kApple);
-            const int a_iters = (p.n_apple + 63) >> 6;
-            const uint32_t safe = (uint32_t)(WP + 1);                               // cell (1,1)
-            uint32_t waste_cell = 0xFFFFFFFFu;
-            uint32_t waste_count = 0;                                               // #'H' the probabilities were computed from
-            if (!SSD_SKIP(3)) {
-            if (GAME == 0) {
-                // harvest.py:75-104 spawn_apples.  Apple points are interior cells (the border is wall),
-                // so the 3x3 neighbourhood (j*j + k*k <= 2 on the radius-2 box, :90-92) is always in bounds.
-                // Threshold by neighbour count as a sum of steps on n >= k.  (An `n == 0 ? a : n == 1 ? b : ...`
-                // chain is turned into a switch lookup table by the compiler: an indexed vector load from the
-                // kernarg buffer in memory -- an L2 round trip per list entry on the critical path.)
-                const uint32_t t0 = p.thr_h32[0], d1 = p.thr_h32[1] - t0, d2 = p.thr_h32[2] - p.thr_h32[1],
-                               d3 = p.thr_h32[3] - p.thr_h32[2];
-                // 3x3 apple count, threshold and keyed draw of one candidate cell (:90-103)
-                auto wins = [&](uint32_t ce) -> bool {
-                    const int c = (int)(ce & 0xFFFFu);
-                    uint32_t n = 0;
-#pragma unroll
-                    for (int dr = -1; dr <= 1; ++dr)
-#pragma unroll
-                        for (int dc = -1; dc <= 1; ++dc)
-                            if (dr != 0 || dc != 0) n += s_world[c + dr * WP + dc] == 'A';
-                    const uint32_t thr = t0 + (n >= 1 ? d1 : 0u) + (n >= 2 ? d2 : 0u) + (n >= 3 ? d3 : 0u);   // SPAWN_PROB[min(n, 3)]
-                    const bool always = ((p.thr_h_always >> (n < 3 ? n : 3u)) & 1u) != 0;
-                    return (draw(pk_apple, ce >> 16) < thr) | always;
-                };
-                // Pass 1 (cheap): which list entries are candidates at all -- an empty cell nobody stands on (:88).
-                bool el[kListRegs];
-                uint64_t em[kListRegs];
-                int total = 0;
-#pragma unroll
-                for (int j = 0; j < kListRegs; ++j) {
-                    const bool valid = lane + 64 * j < p.n_apple;
-                    const uint32_t c = (valid ? alist[j] : safe) & 0xFFFFu;
-                    el[j] = valid & (s_world[c] != 'A') & (s_occ[c] == 0);
-                    em[j] = ballot(el[j]);
-                    total += __builtin_popcountll(em[j]);
-                }
-                if (a_iters <= kListRegs && total <= 64) {
-                    // Usual case: at most 64 candidates among the (up to 192) apple points.  Compact them through
-                    // 128 B of LDS scratch so that ONE pass of lanes does the stencil + draw instead of three.
-                    if (total) {
-                        int base = 0;
-#pragma unroll
-                        for (int j = 0; j < kListRegs; ++j) {
-                            const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(em[j] >> 32),
-                                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)em[j], 0u));
-                            if (el[j]) s_tmp[slot] = alist[j];
-                            base += __builtin_popcountll(em[j]);
-                        }
-                        wave_sync();
-                        const bool mine = lane < total;
-                        const uint32_t c = mine ? s_tmp[lane] : safe;
-                        const bool hit = mine & wins(c);
-                        wave_sync();                                                // every count used the pre-spawn map (:73)
-                        if (hit) s_world[c & 0xFFFFu] = 'A';
-                    }
-                } else {
-                    // general form: every lane evaluates its own list entries
-#pragma unroll
-                    for (int j = 0; j < kListRegs; ++j) {
-                        const uint32_t c = el[j] ? alist[j] : safe;
-                        spawn_bits |= (el[j] & wins(c)) ? bit(j) : 0ull;
-                    }
-                    for (int j = kListRegs; j < a_iters; ++j) {
-                        const int idx = lane + 64 * j;
-                        const bool valid = idx < p.n_apple;
-                        const uint32_t c = valid ? p.apple_cells[idx] : safe;
-                        const bool cand = valid & (s_world[c & 0xFFFFu] != 'A') & (s_occ[c & 0xFFFFu] == 0);
-                        spawn_bits |= (cand & wins(c)) ? bit(j) : 0ull;
-                    }
-                }
-            } else {
-                // cleanup.py:113-116: compute_probabilities (:156-171) from the current waste count, then
-                // spawn_apples_and_waste (:132-154).  Thresholds come from a host-computed table.
-                uint32_t nh = 0;
-                for (int i = lane * 16; i < S; i += 64 * 16) {
-                    const uint4 qd = *reinterpret_cast<const uint4 *>(s_world + i);
-                    nh += count_bytes_eq(qd.x, 'H') + count_bytes_eq(qd.y, 'H') + count_bytes_eq(qd.z, 'H') + count_bytes_eq(qd.w, 'H');
-                }
-                nh = wave_sum_u32(nh);                                              // compute_permitted_area (:173-179)
-                waste_count = nh;
-                nh = nh < (uint32_t)p.n_thr ? nh : (uint32_t)p.n_thr - 1;
-                const uint64_t thr_a = p.thr_ca[nh], thr_w = p.thr_cw[nh];
-                auto apple = [&](int j, uint32_t c, bool valid) {                   // :135-141
-                    c = valid ? c : safe;
-                    const uint8_t w = s_world[c & 0xFFFFu], o = s_occ[c & 0xFFFFu];
-                    const bool hit = valid & (w != 'A') & (o == 0) & ((uint64_t)draw(pk_apple, c >> 16) < thr_a);
-                    spawn_bits |= hit ? bit(j) : 0ull;
-                };
-#pragma unroll
-                for (int j = 0; j < kListRegs; ++j) apple(j, alist[j], lane + 64 * j < p.n_apple);
-                for (int j = kListRegs; j < a_iters; ++j) {
-                    const int idx = lane + 64 * j;
-                    apple(j, idx < p.n_apple ? p.apple_cells[idx] : 0u, idx < p.n_apple);
-                }
-                if (thr_w) {
-                    // :144-153 shuffled scan, first non-'H' point whose coin succeeds (at most one per step):
-                    // order = ascending (ORDER draw, cell), coin keyed by cell.
-                    const uint32_t pk_coin = phase_key(key, t, kWasteCoin), pk_ord = phase_key(key, t, kWasteOrder);
-                    bool has = false;
-                    uint32_t bh = 0, bl = 0;
-                    auto waste = [&](uint32_t ce, bool valid) {
-                        ce = valid ? ce : safe;
-                        const uint32_t c = ce & 0xFFFFu;                             // ties break on the cell: grid and dense order agree
-                        const bool cand = valid & (s_world[c] != 'H') & ((uint64_t)draw(pk_coin, ce >> 16) < thr_w);
-                        const uint32_t kh = draw(pk_ord, ce >> 16);
-                        const bool better = cand & (!has | (kh < bh) | ((kh == bh) & (c < bl)));
-                        bh = better ? kh : bh; bl = better ? c : bl; has = has | cand;
-                    };
-                    const int w_iters = (p.n_waste + 63) >> 6;
-#pragma unroll
-                    for (int j = 0; j < kListRegs; ++j) waste(wlist[j], lane + 64 * j < p.n_waste);
-                    for (int j = kListRegs; j < w_iters; ++j) {
-                        const int idx = lane + 64 * j;
-                        waste(idx < p.n_waste ? p.waste_cells[idx] : 0u, idx < p.n_waste);
-                    }
-                    uint32_t oh, ol;
-                    if (wave_argmin_pair(has, bh, bl, oh, ol)) waste_cell = ol;
-                }
-            }
-            }
-            wave_sync();                                                            // counts use the pre-spawn map (harvest.py:73)
-#pragma unroll
-            for (int j = 0; j < kListRegs; ++j)
-                if ((spawn_bits >> j) & 1) s_world[alist[j] & 0xFFFFu] = 'A';
-            for (int j = kListRegs; j < a_iters; ++j)
-                if ((spawn_bits >> j) & 1) s_world[p.apple_cells[lane + 64 * j] & 0xFFFFu] = 'A';
-            if (waste_cell != 0xFFFFFFFFu) s_world[waste_cell] = 'H';               // may land under an agent
-            wave_sync();
-
-            SSD_STAMP(5);   // respawn
-            // ---- write the env back: grid, agents, header, rewards, dones ----
+        // The grid, agents and header go back to HBM once per launch: right after the respawn of a step / reset launch,
+        // after the last step of a rollout launch.
+        uint32_t waste_last = 0;
+        auto write_state = [&]() {
             uint8_t *gw = p.world + (size_t)e * S;
             for (int i = lane * 16; i < S; i += 64 * 16) {
                 *reinterpret_cast<uint4 *>(gw + i) = *reinterpret_cast<const uint4 *>(s_world + i);
                 if (keep_beams)
                     *reinterpret_cast<uint4 *>(p.beam + (size_t)e * S + i) = *reinterpret_cast<const uint4 *>(s_beam + i);
             }
-            if (is_agent) {
-                p.agents[(size_t)e * N + lane] = cell | (orient << 16);
-                if (mode == kModeStep) {
-                    if (p.rew) p.rew[(size_t)e * N + lane] = rew;                   // compute_reward (:208)
-                    // get_done -> False (:209); with a horizon set, the episode ends after `horizon` steps
-                    if (p.done) p.done[(size_t)e * N + lane] = (p.horizon > 0 && t >= (uint32_t)p.horizon) ? 1 : 0;
-                }
-            }
-            if (lane == 0) p.hdr[e] = make_uint4(key, t, episode, waste_count);
+            if (is_agent) p.agents[(size_t)e * N + lane] = cell | (orient << 16);
+            if (lane == 0) p.hdr[e] = make_uint4(key, t, episode, waste_last);
             if (status && lane == 0) atomicOr(p.status, status);
-            wave_sync();
+        };
+        // ---- One pass = one reset or one step of the env.  A step / reset / observe launch makes one pass.  A rollout
+        //      launch (rollout.py:58-70) loops: [reset pass when one is due,] step pass, ... with the env resident in LDS
+        //      and registers; every step pass writes its observations / rewards / dones to its slot of the output ring. ----
+        int k_step = 0;                                       // steps done so far (rollout)
+        int to_reset = -1;                                    // steps until the next reset is due (rollout; < 0: never)
+        uint32_t slot = 0;                                    // output ring slot of the current step (rollout)
+        if (roll) {
+            if (p.reset_every > 0) to_reset = (p.reset_every - p.step0 % p.reset_every) % p.reset_every;
+            slot = (uint32_t)(p.step0 % p.ring);
         }
-
-        SSD_STAMP(6);   // write-back issued
-        // ---- get_map_with_agents (map_env.py:280-302): world <- agents <- beams, in place, 4 cells per op ----
-        for (int i = lane * 4; i < S; i += 64 * 4) {
-            const uint32_t w = *reinterpret_cast<const uint32_t *>(s_world + i);
-            const uint32_t o = *reinterpret_cast<const uint32_t *>(s_occ + i);
-            const uint32_t b = *reinterpret_cast<const uint32_t *>(s_beam + i);
-            const uint32_t mo = nonzero_bytes(o), mb = nonzero_bytes(b);
-            uint32_t v = (w & ~mo) | (o & mo);
-            v = (v & ~mb) | (b & mb);
-            *reinterpret_cast<uint32_t *>(s_world + i) = v;
-        }
-        wave_sync();
-        SSD_STAMP(7);   // overlay built
-        SSD_STAMP(8);
-
-        // ---- per-agent observations (agent.py:76-78 -> utility_funcs.py:59-114 window with '0' padding,
-        //      map_env.py:316-339 colour LUT, :669-689 rotate_view).  The wave renders its own env's agents
-        //      one after the other: lane = 4 consecutive cells of the V x V view (12 contiguous output
-        //      bytes), so the view coordinates are per-lane constants, the agent's position and rotation
-        //      are scalars, and one wave store covers up to 768 contiguous bytes of the uint8 obs tensor.
-        //      Thanks to the padded grid layout a view cell is ONE multiply-add away from its LDS address.
-        //      An agent's block starts at a multiple of V*V*3 = 675 bytes, i.e. at any byte alignment:
-        //      the 12-byte stores rely on gfx9's unaligned global access. ----
-        if (p.obs) {
-            typedef __attribute__((address_space(3))) const uint8_t lds_u8;
-            const int V = STD ? 15 : p.V, v = STD ? 7 : p.view_len, VV = V * V;
-            // (diagnostic builds, skip bit 4: all envs write the first 64 envs' blocks -- same instructions, no HBM write stream)
-            uint8_t *out_env = p.obs + (size_t)(SSD_SKIP(4) ? (e & 63) : e) * N * VV * 3;
-            // Per-agent constants, computed once with lane = agent and read back as scalars in the loop.
-            // Window cell (a, b) of an agent on grid cell `cell` is grid cell cell + (a - v) * WP + (b - v).
-            // The view is rot90^k of the window (rotate_view, map_env.py:669-689; UP 0, LEFT 1, DOWN 2,
-            // RIGHT 3; reset observations are not rotated): view cell (i, j) shows window cell
-            //   k=0 (i, j)   k=1 (j, V-1-i)   k=2 (V-1-i, V-1-j)   k=3 (V-1-j, i)
-            // i.e. with lin0 = i*WP + j, lin1 = j*WP + (V-1-i) and C = (V-1)*(WP+1):
-            //   address = base + lin0 | base + lin1 | base + C - lin0 | base + C - lin1,   base = cell - v*(WP+1).
-            uint32_t a_s0 = 0, a_k = 0;
-            if (is_agent) {
-                a_k = (mode == kModeStep || p.rotate) ? (orient == 2 ? 0u : orient == 0 ? 1u : orient == 3 ? 2u : 3u) : 0u;
-                a_s0 = (uint32_t)((int)cell - v * (WP + 1) + (a_k >= 2 ? (V - 1) * (WP + 1) : 0));
-            }
-            const uint32_t world_lds = (uint32_t)(uintptr_t)(lds_u8 *)s_world;      // LDS byte address of grid cell 0
-            for (int base = 0; base < VV; base += 256) {
-                // A lane renders 4 consecutive cells = one 12-byte store.  V*V is not a multiple of 4 (225 = 56*4 + 1):
-                // the lane holding the leftover cells starts 4 cells before the end instead, re-rendering up to 3
-                // cells of its neighbour (same bytes, written twice) so that EVERY store is a full 12 bytes and the
-                // wave never takes a divergent byte-store path.  Views under 4 cells (view_len 0) use byte stores.
-                const int pp_raw = base + 4 * lane;
-                const bool lane_on = pp_raw < VV;
-                const int pp0 = (VV >= 4 && pp_raw > VV - 4) ? VV - 4 : pp_raw;     // lanes past the end repeat the last one
-                int L0[4], L1[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int pp = pp0 + q;
-                    const int i = STD ? pp / 15 : (int)(((uint32_t)pp * p.v_magic16) >> 16), j = pp - i * V;   // pp / V, pp % V
-                    // 24-bit multiply-adds (full rate; a plain `*` becomes a quarter-rate 32-bit multiply here)
-                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(L0[q]) : "v"(i), "s"(WP), "v"(j));
-                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(L1[q]) : "v"(j), "s"(WP), "v"(V - 1 - i));
+        bool in_reset = roll && to_reset == 0;
+        for (;;) {
+            const bool is_reset = roll ? in_reset : (mode == kModeReset);
+            const bool is_step = roll ? !in_reset : (mode == kModeStep);
+            const size_t slot_en = roll ? (size_t)slot * (size_t)p.E_total * N : 0;     // element offset of the slot in rew / done
+            if (roll) {
+                // a fresh pass over the resident env: default priority, empty beam / occupancy layers, and on a reset
+                // the grid of reset_map() (:560-564) + custom_reset
+                __builtin_amdgcn_s_setprio(0);
+                rew = 0;
+                for (int i = lane * 16; i < S; i += 64 * 16) {
+                    if (is_reset) *reinterpret_cast<uint4 *>(s_world + i) = *reinterpret_cast<const uint4 *>(p.reset_world + i);
+                    *reinterpret_cast<uint4 *>(s_beam + i) = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4 *>(s_occ + i) = make_uint4(0, 0, 0, 0);
                 }
-                uint32_t off3 = (uint32_t)pp0 * 3u;                                 // byte offset of the lane's cells in an agent's block
-                asm volatile("" : "+v"(off3));                                      // keep it in a register (else re-derived per agent)
-                const int ncell = lane_on ? VV - pp0 : 0;                           // >= 4 whenever VV >= 4
-                if (STD && NA > 0 && NA % 5 == 0 && !F32) {
-                    // Specialised kernels: five agents per pass.  All their grid reads go out together, then all the
-                    // colour-table reads, then the stores: two LDS round trips per pass instead of two per agent.
-                    constexpr int kB = 5;
-                    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-                    struct __attribute__((packed, aligned(1))) P3 { u32x3 v; };
-                    for (int ag0 = 0; ag0 < NA; ag0 += kB) {
-                        uint32_t addr[kB][4], px[kB][4];
-#pragma unroll
-                        for (int u = 0; u < kB; ++u) {
-                            const uint32_t k = rl(a_k, ag0 + u);
-                            const uint32_t s0 = rl(a_s0, ag0 + u) + world_lds;
-                            const int sgn = k >= 2 ? -1 : 1;
-                            if (k & 1) {
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[u][q]) : "v"(L1[q]), "v"(sgn), "s"(s0));
-                            } else {
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[u][q]) : "v"(L0[q]), "v"(sgn), "s"(s0));
-                            }
-                        }
-                        uint32_t gl[kB][4];
-#pragma unroll
-                        for (int u = 0; u < kB; ++u)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) gl[u][q] = *(lds_u8 *)(uintptr_t)addr[u][q];
-#pragma unroll
-                        for (int u = 0; u < kB; ++u)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) px[u][q] = s_lut[gl[u][q]];
-                        if (lane_on) {
-#pragma unroll
-                            for (int u = 0; u < kB; ++u) {
-                                u32x3 d;
-                                d.x = __builtin_amdgcn_perm(px[u][1], px[u][0], 0x04020100u);   // r0 g0 b0 r1
-                                d.y = __builtin_amdgcn_perm(px[u][2], px[u][1], 0x05040201u);   // g1 b1 r2 g2
-                                d.z = __builtin_amdgcn_perm(px[u][3], px[u][2], 0x06050402u);   // b2 r3 g3 b3
-                                reinterpret_cast<P3 *>(out_env + (size_t)(ag0 + u) * VV * 3 + off3)->v = d;
-                            }
+                wave_sync();
+            }
+            if (is_reset) {
+                // ---- MapEnv.reset (map_env.py:214-249) ----
+                episode += 1; t = 0;
+                key = env_key(p.seed_lo, p.seed_hi, p.env_base + (uint32_t)e, episode);
+                // the grid loaded above is reset_map (:560-564) + custom_reset of the base map
+                // setup_agents (harvest.py:46-55 / cleanup.py:118-130): spawn_point (map_env.py:651-662) takes
+                // the LAST free point of a fresh shuffle = the free point with the largest (draw, cell);
+                // spawn_rotation (:664-667) indexes [LEFT, RIGHT, UP, DOWN].
+                const uint32_t pk_pt = phase_key(key, 0, kSpawnPoint), pk_rot = phase_key(key, 0, kSpawnRot);
+                for (int i = 0; i < N; ++i) {
+                    bool has = false;
+                    uint32_t bh = 0, bl = 0;                     // lane-local min of (~draw, ~cell) = max of (draw, cell)
+                    for (int s = lane; s < p.n_spawn; s += 64) {
+                        const uint32_t ce = p.spawn_cells[s], c = ce & 0xFFFFu;         // grid index | dense index << 16
+                        if (s_occ[c] == 0) {
+                            const uint32_t kh = ~draw(pk_pt, ((uint32_t)i << 16) | (ce >> 16)), kl = ~c;
+                            if (!has || kh < bh || (kh == bh && kl < bl)) { bh = kh; bl = kl; has = true; }
                         }
                     }
-                } else
-                for (int ag = 0; ag < N; ++ag) {
-                    const uint32_t k = rl(a_k, ag);
-                    const uint32_t s0 = rl(a_s0, ag) + world_lds;
-                    const int sgn = k >= 2 ? -1 : 1;                                // one VGPR per agent: v_mad takes one scalar operand
-                    uint32_t addr[4], px[4];
-                    // wave-uniform branch on the rotation's parity instead of a per-cell select (the asm is volatile so
-                    // that the two arms are not merged back into selects)
-                    if (k & 1) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[q]) : "v"(L1[q]), "v"(sgn), "s"(s0));
+                    uint32_t oh, ol, chosen;
+                    if (wave_argmin_pair(has, bh, bl, oh, ol)) chosen = ~ol;
+                    else { status |= kStNoSpawn; chosen = p.n_spawn ? (p.spawn_cells[0] & 0xFFFFu) : (uint32_t)(WP + 1); }
+                    if (lane == i) { cell = chosen; orient = randint(draw(pk_rot, (uint32_t)i), 4); }
+                    s_occ[chosen] = agent_glyph((uint32_t)i);    // all lanes, same address, same value
+                    wave_sync();
+                }
+            }
+
+            SSD_STAMP(1);   // state loaded
+            int act = -1;
+            uint32_t ordv = (uint32_t)lane;                      // action order list, lane k = k-th acting agent
+            int nord = N;
+            if (is_step) {
+                t += 1;
+                // ---- actions (map_env.py:171-173) ----
+                if (p.num_actions_random > 0) {                  // rollout.py:64-65 uniform random actions
+                    const uint32_t pk = phase_key(key, t, kAction);
+                    if (is_agent) {
+                        act = (int)randint(draw(pk, (uint32_t)lane), (uint32_t)p.num_actions_random);
+                        if (p.actions_out) p.actions_out[(size_t)e * N + lane] = act;
+                    }
+                } else {
+                    act = act_in;
+                }
+                constexpr int kNumActions = GAME == 0 ? 8 : 9;   // harvest.py:44, cleanup.py:70
+                const bool bad = is_agent && (act < -1 || act >= kNumActions);
+                if (ballot(bad)) { status |= kStBadAction; if (bad) act = -1; }
+                if (has_order) {
+                    ordv = ord_in;
+                    if (ordv != 0xFFu && ordv >= (uint32_t)N) { ordv = 0xFFu; status |= kStBadAction; }
+                    const uint64_t endm = ballot(ordv == 0xFFu);
+                    nord = endm ? __builtin_ctzll(endm) : 64;
+                    uint64_t acting = 0;
+                    for (int k = 0; k < nord; ++k) acting |= bit(rl(ordv, k));
+                    if (!((acting >> lane) & 1)) act = -1;       // agents absent from the action dict do nothing
+                }
+
+                // A launch lasts as long as its slowest wave.  How long a wave will take is known here: in Cleanup every
+                // beam costs ~0.5 us (they are traced one after the other), the conflict path of the moves ~1.5 us.  Waves
+                // with more work ahead issue ahead of the waves they share a SIMD with (which have slack); measured
+                // -0.5 us per 4096-env launch.  (Harvest traces all beams at once: no priority needed for them.)
+                if (GAME == 1) {
+                    constexpr int kFireAct = 7, kCleanAct = 8;
+                    const int ns = __builtin_popcountll(ballot(is_agent && (act == kFireAct || act == kCleanAct)));
+                    if (ns >= 2) __builtin_amdgcn_s_setprio(2);
+                    else if (ns == 1) __builtin_amdgcn_s_setprio(1);
+                }
+                // ---- update_moves (map_env.py:357-543) ----
+                const bool mover = !SSD_SKIP(0) && is_agent && act >= 0 && act <= 4;              // :383
+                if (is_agent && (act == 5 || act == 6)) orient = turn(act, orient);   // :390-392
+                uint32_t tcell = cell;
+                {   // every lane runs this (non-movers get a zero step), so the wall read is one unconditional LDS load.
+                    // MOVE_* vectors (map_env.py:11-15) and rotate_action (:701-716: UP v, LEFT (vc,-vr), RIGHT (-vc,vr),
+                    // DOWN -v) as arithmetic on a cyclic direction index (0 (-1,0), 1 (0,1), 2 (1,0), 3 (0,-1)): the
+                    // move code picks an index, the orientation adds a quarter-turn count.  Tables are 5-bit fields
+                    // holding 8 * index, so the sum (mod 32, which the bit-field extract applies by itself) is the
+                    // bit offset of the result's byte.
+                    constexpr uint32_t kMoveIdx8 = (0u << 0) | (16u << 5) | (24u << 10) | (8u << 15);   // MOVE_* codes 0..3
+                    constexpr uint32_t kTurns8 = (8u << 0) | (24u << 5) | (0u << 10) | (16u << 15);     // LEFT, RIGHT, UP, DOWN
+                    const uint32_t sum = __builtin_amdgcn_ubfe(kMoveIdx8, (uint32_t)act * 5u, 5u) + __builtin_amdgcn_ubfe(kTurns8, orient * 5u, 5u);
+                    int step;
+                    if (FAST) {                                  // row stride fits a signed byte: the table holds the cell offsets
+                        const uint32_t off4 = ((uint32_t)(-WP) & 0xFFu) | (1u << 8) | ((uint32_t)WP << 16) | (0xFFu << 24);
+                        step = __builtin_amdgcn_sbfe(off4, sum, 8u);
                     } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[q]) : "v"(L0[q]), "v"(sgn), "s"(s0));
+                        step = __builtin_amdgcn_sbfe(0x000100FFu, sum, 8u) * WP + __builtin_amdgcn_sbfe(0xFF000100u, sum, 8u);
                     }
-                    // a cell outside the map reads the '0' of the row padding / aprons (utility_funcs.py:94-114)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) px[q] = s_lut[*(lds_u8 *)(uintptr_t)addr[q]];
-                    const size_t cell0 = (size_t)ag * VV + pp0;                     // first of this lane's cells within the env
-                    if (obs_f32) {
-                        // float32 mode: 3 floats per cell through the exact byte -> float table, 48 contiguous
-                        // bytes per lane (three 16-byte stores; an agent block starts at a multiple of 2700 B)
-                        float *dstf = reinterpret_cast<float *>(p.obs) + ((size_t)e * N * VV + cell0) * 3;
-                        float f[12];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            f[q * 3 + 0] = s_f32[px[q] & 0xFFu];
-                            f[q * 3 + 1] = s_f32[(px[q] >> 8) & 0xFFu];
-                            f[q * 3 + 2] = s_f32[(px[q] >> 16) & 0xFFu];
+                    const uint32_t cand = (uint32_t)((int)cell + ((mover & (act < 4)) ? step : 0));    // STAY (4) is a zero step
+                    // agent.py:105-113 return_valid_pos (the agent's grid agrees with world_map on '@')
+                    tcell = (mover & (s_world[cand] != '@')) ? cand : cell;
+                }
+                uint32_t mvcell = tcell;                         // agent_moves[id] (:410)
+                const uint64_t M = ballot(mover);
+                // Fast path.  If no mover's target is a cell some OTHER agent stands on and no two movers
+                // share a target, every branch of :424-543 degenerates to "each mover takes its target"
+                // whatever the shuffle says (STAY / wall-blocked movers target their own cell and stay), and
+                // since draws are counter-keyed there is no RNG state to advance.  Otherwise run the
+                // reference algorithm in full.
+                const uint64_t agents_m = N >= 64 ? ~0ull : bit((uint32_t)N) - 1;
+                uint64_t clashm = 0, dupm = 0;                   // lanes (!= j) whose target is agent j's cell or mover j's target
+                for (int j = 0; j < N; ++j) {
+                    const uint32_t cj = rl(cell, j), tj = rl(tcell, j);
+                    const uint64_t on_cell = ballot(tcell == cj), on_target = (((M >> j) & 1) ? ballot(tcell == tj) : 0ull) & ~bit(j);
+                    clashm |= (on_cell & ~bit(j)) | on_target;
+                    dupm |= on_target;
+                }
+                const bool slow = (clashm & M) != 0;
+                SSD_NOTE(12, slow ? 1 : 0);
+                if (!slow) {
+                    if (mover) cell = tcell;
+                } else {                                         // :415 (M != 0 here)
+                    __builtin_amdgcn_s_setprio(3);               // the slowest waves of a launch come through here (1-2 % of the envs)
+                    uint64_t Hm = M;                             // ids that still have an entry in agent_moves
+                    // :424-491 cells wanted by several agents, in lexicographic order (np.unique, axis=0): visited in
+                    // ascending cell order (scalar min over the few lanes involved).  The shuffle of :421-423 only
+                    // decides who wins such a cell, so it is only computed when there is one (draws are counter-keyed).
+                    uint64_t todo = dupm & M;
+                    if (todo) {
+                        const int nm = __builtin_popcountll(M);
+                        uint32_t perm = 0;                       // lane k: k-th entry of the (shuffled) zipped list
+                        {
+                            int cnt = 0;
+                            for (int k = 0; k < nord; ++k) {
+                                const uint32_t a = has_order ? rl(ordv, k) : (uint32_t)k;
+                                if ((M >> a) & 1) { if (lane == cnt) perm = a; ++cnt; }
+                            }
                         }
-                        if (VV >= 4) {
-                            if (lane_on) {
-                                typedef float f32x4 __attribute__((ext_vector_type(4)));
-                                struct __attribute__((packed, aligned(4))) F4 { f32x4 v; };
-#pragma unroll
-                                for (int k4 = 0; k4 < 3; ++k4) {
-                                    f32x4 v4 = {f[4 * k4], f[4 * k4 + 1], f[4 * k4 + 2], f[4 * k4 + 3]};
-                                    reinterpret_cast<F4 *>(dstf + 4 * k4)->v = v4;
+                        const uint32_t pk = phase_key(key, t, kMove);
+                        for (int i = nm - 1; i >= 1; --i) {      // :421-423 np.random.shuffle = Fisher-Yates from the end
+                            const uint32_t j = randint(draw(pk, (uint32_t)i), (uint32_t)i + 1);
+                            const uint32_t vi = rl(perm, i), vj = rl(perm, j);
+                            if (lane == i) perm = vj;
+                            if (lane == (int)j) perm = vi;
+                        }
+                        while (todo) {
+                            uint32_t nxt = 0xFFFFFFFFu;
+                            for (uint64_t m = todo; m; m &= m - 1) nxt = umin(nxt, rl(tcell, __builtin_ctzll(m)));
+                            const uint64_t Cm = ballot(mover && tcell == nxt);          // contenders (:441-442)
+                            todo &= ~Cm;
+                            bool cell_free = true;
+                            const uint64_t Pm = ballot(is_agent && cell == nxt);        // :449 move in self.agent_pos
+                            if (Pm) {
+                                const uint32_t occ = 63 - __builtin_clzll(Pm);          // agent_by_pos: last index wins
+                                const uint32_t occ_mv = rl(mvcell, occ);
+                                if ((Cm >> occ) & 1) cell_free = false;                 // (1) :460
+                                else if (!((Hm >> occ) & 1) || occ_mv == nxt) cell_free = false;    // (2) :466-468
+                                else if (ballot(__builtin_amdgcn_inverse_ballot_w64(Cm) && cell == occ_mv)) cell_free = false; // (3) :472-476
+                            }
+                            if (cell_free) {                     // :480-483 first contender in shuffled order moves NOW
+                                uint32_t w = 0;
+                                for (int k = 0; k < nm; ++k) { w = rl(perm, k); if ((Cm >> w) & 1) break; }
+                                if (lane == (int)w) cell = nxt;
+                            }
+                            if (__builtin_amdgcn_inverse_ballot_w64(Cm)) mvcell = cell;   // :486-491 every contender's move becomes "stay"
+                        }
+                    }
+                    // :494-543 remaining moves: chains, swaps, cycles.  Who stands on each agent's target, and does any cell
+                    // hold two agents (possible after a contested cell was entered while its occupant was still there)?
+                    uint64_t overlap = 0;
+                    int occ_of_target = -1;
+                    for (int j = 0; j < N; ++j) {
+                        const uint32_t cj = rl(cell, j);
+                        occ_of_target = (mvcell == cj) ? j : occ_of_target;
+                        overlap |= ballot(cell == cj) & agents_m & ~bit(j);
+                    }
+                    if (!overlap) {
+                        // Usual case: every cell holds at most one agent and (after the step above) no two pending moves
+                        // share a target, so "a waits for the agent on its target" is a graph of disjoint paths and cycles,
+                        // and the pass loop of :494-543 comes out as: a path moves as a whole iff its head's target is free;
+                        // it stays as a whole if it ends at an agent that is not moving; a 2-cycle (swap, :524-530) stays;
+                        // longer cycles rotate (:540-543).  Resolved by pointer jumping over lanes, ceil(log2 N) rounds.
+                        const bool pend = __builtin_amdgcn_inverse_ballot_w64(Hm) & (mvcell != cell);
+                        int st = pend ? (occ_of_target < 0 ? 1 : 2) : 0;                // 0 stays, 1 moves, 2 waits for lane `nx`
+                        const int nx0 = (occ_of_target & 63) << 2;
+                        int nx = nx0;
+                        for (int r = 1; r < N; r <<= 1) {
+                            const int s2 = __builtin_amdgcn_ds_bpermute(nx, st), n2 = __builtin_amdgcn_ds_bpermute(nx, nx);
+                            const bool waiting = st == 2;
+                            st = (waiting & (s2 != 2)) ? s2 : st;
+                            nx = (waiting & (s2 == 2)) ? n2 : nx;
+                        }
+                        if (ballot(st == 2)) {                                          // still waiting: on a cycle
+                            const int back = __builtin_amdgcn_ds_bpermute(nx0, nx0);    // my target's target ...
+                            st = st == 2 ? (back == (lane << 2) ? 0 : 1) : st;          // ... is me: a swap
+                        }
+                        if (st == 1) cell = mvcell;
+                    } else
+                    while (Hm) {
+                        const uint32_t snap_cell = cell, snap_mv = mvcell;              // agent_by_pos (:495), moves_copy (:498)
+                        const uint64_t snapH = Hm;
+                        uint64_t del = 0;
+                        const int n0 = __builtin_popcountll(Hm);
+                        for (int k = 0; k < nord; ++k) {                                // agent_moves insertion order = action order
+                            const uint32_t a = has_order ? rl(ordv, k) : (uint32_t)k;
+                            if (!((snapH >> a) & 1) || ((del >> a) & 1)) continue;      // :500-502
+                            const uint32_t m = rl(snap_mv, a);
+                            if (ballot(is_agent && cell == m)) {                        // :503 (live positions)
+                                const uint64_t sm = ballot(is_agent && snap_cell == m); // :506 (pass-start snapshot)
+                                if (!sm) { status |= kStMoveLookup; Hm &= ~bit(a); del |= bit(a); continue; }
+                                const uint32_t occ = 63 - __builtin_clzll(sm);
+                                const uint32_t ccp = rl(cell, occ), occ_mv = rl(mvcell, occ);
+                                const uint32_t cm = ((Hm >> occ) & 1) ? occ_mv : ccp;   // :509
+                                const uint32_t pa = rl(cell, a);
+                                if (a == occ) { Hm &= ~bit(a); del |= bit(a); }         // (1) :512-514
+                                else if (!((snapH >> occ) & 1) || ccp == cm) { Hm &= ~bit(a); del |= bit(a); }  // (2) :518-521
+                                else if (occ_mv == pa && m == ccp) {                    // (3) :524-530 swap: both give up
+                                    Hm &= ~(bit(a) | bit(occ)); del |= bit(a) | bit(occ);
+                                }
+                            } else {                                                    // :532-535
+                                if (lane == (int)a) cell = m;
+                                Hm &= ~bit(a); del |= bit(a);
+                            }
+                        }
+                        if (__builtin_popcountll(Hm) == n0) {    // :540-543 only cycles are left: rotate them
+                            if (__builtin_amdgcn_inverse_ballot_w64(Hm)) cell = mvcell;
+                            break;
+                        }
+                    }
+                }
+            }
+
+            SSD_STAMP(2);   // moves resolved
+            uint64_t highest = 0;                                // agents that are the highest index on their cell (agent_by_pos, :603)
+            if (!is_reset && !SSD_SKIP(1)) {
+                // ---- consume (map_env.py:178-181, agent.py:177-183) + occupancy layer ----
+                // Index order means: of several agents on one cell the LOWEST index eats the apple, and
+                // agent_by_pos / the overlay show the HIGHEST index (:289-297, :603).
+                // Wave masks on the scalar unit: agent j is the lowest (highest) index on its cell iff no lower (higher)
+                // bit is set among the agents standing where it stands.
+                const uint64_t agents = N >= 64 ? ~0ull : bit((uint32_t)N) - 1;
+                uint64_t lowest = 0;
+                for (int j = 0; j < N; ++j) {
+                    const uint64_t here = ballot(cell == rl(cell, j)) & agents;
+                    lowest |= (here & (bit(j) - 1)) ? 0ull : bit(j);
+                    highest |= ((here >> j) >> 1) ? 0ull : bit(j);
+                }
+                const bool eats = is_step & __builtin_amdgcn_inverse_ballot_w64(lowest) & (s_world[cell] == 'A');
+                if (eats) { s_world[cell] = ' '; rew += 1; }
+                if (__builtin_amdgcn_inverse_ballot_w64(highest)) s_occ[cell] = agent_glyph((uint32_t)lane);
+                wave_sync();
+            }
+
+            SSD_STAMP(3);   // consume + occupancy
+            if (is_step) {
+                // ---- update_custom_moves (map_env.py:545-552): beams in action order ----
+                const int L = STD ? 5 : p.beam_len;
+                const uint32_t rmask = (1u << L) - 1u;
+                constexpr int kFire = 7, kClean = 8;
+                uint64_t shooters = SSD_SKIP(2) ? 0ull : ballot(is_agent && (act == kFire || (GAME == 1 && act == kClean)));
+                SSD_NOTE(13, __builtin_popcountll(shooters));
+                if (GAME == 0 && shooters) {
+                    // Harvest: a FIRE beam changes nothing another beam reads (no cell types, no blocking cells, harvest.py:62-67;
+                    // 'F' marks and penalties commute), so the rays of up to 64 / 3L shooters are traced in ONE pass:
+                    // lane = (shooter slot g, ray q, step kk).  A wave with three shooters costs what one shooter costs.
+                    const int R = 3 * L, G = STD ? 4 : 64 / R;
+                    const int g = STD ? lane / 15 : lane / R, r = lane - g * R;
+                    const int q = (r >= L) + (r >= 2 * L), kk = r - q * L;
+                    const int cq = q == 1 ? 1 : q == 2 ? -1 : 0, ck = kk + (q == 0);   // ray cell = pos + cq * right + ck * d (:608-609)
+                    const int sh = g * R + q * L;                                       // first lane of this lane's ray
+                    if (is_agent && act == kFire) rew -= 1;                             // agent.py:170-172 fire_beam('F')
+                    const uint32_t packed_agent = cell | (orient << 16);
+                    while (shooters) {
+                        int a = -1, taken = 0;                                          // slot g <- the g-th remaining shooter
+                        for (; taken < G && shooters; ++taken) {
+                            const int b = __builtin_ctzll(shooters);
+                            a = (g == taken) ? b : a;
+                            shooters &= shooters - 1;
+                        }
+                        const bool inray = a >= 0;
+                        const uint32_t ar = (uint32_t)__builtin_amdgcn_ds_bpermute((inray ? a : 0) << 2, (int)packed_agent);
+                        const int pc = (int)(ar & 0xFFFFu);
+                        const uint32_t o8 = (ar >> 16) << 3;                            // orientation code * 8: LEFT RIGHT UP DOWN
+                        int dlin, rlin;                                                 // d and rotate_right(d) = (-dc, dr) (:607) as cell offsets
+                        if (FAST) {
+                            const uint32_t b = (uint32_t)WP & 0xFFu, nb = (uint32_t)(-WP) & 0xFFu;
+                            dlin = __builtin_amdgcn_sbfe(nb | (b << 8) | (0xFFu << 16) | (1u << 24), o8, 8u);   // -WP, WP, -1, 1
+                            rlin = __builtin_amdgcn_sbfe(0xFFu | (1u << 8) | (b << 16) | (nb << 24), o8, 8u);   // -1, 1, WP, -WP
+                        } else {
+                            const int dr = __builtin_amdgcn_sbfe(0x000001FFu, o8, 8u), dc = __builtin_amdgcn_sbfe(0x01FF0000u, o8, 8u);
+                            dlin = dr * WP + dc; rlin = -dc * WP + dr;
+                        }
+                        // The map's border is wall and a ray ends at the first '@' (:616), so the in-bounds test of :615 can
+                        // never be what stops it: cells past the wall are read (harmlessly) and ignored by the first-stop logic.
+                        const int cidx = inray ? pc + __mul24(rlin, cq) + __mul24(dlin, ck) : WP + 1;
+                        const uint8_t wch = s_world[cidx], och = s_occ[cidx];
+                        const bool pass = inray & (wch != '@');                         // :616
+                        const bool stopper = pass & (och != 0);                         // :621 agents absorb the beam
+                        const uint64_t mf = ballot(inray & !pass), ms = ballot(stopper);
+                        const uint32_t f = (uint32_t)(mf >> sh) & rmask, st = (uint32_t)(ms >> sh) & rmask;
+                        const int ff = f ? __builtin_ctz(f) : L, fs = st ? __builtin_ctz(st) : L;
+                        const int len = fs < ff ? fs + 1 : ff;                          // beam covers the stopping cell
+                        if (inray && kk < len) s_beam[cidx] = 'F';                      // :624 firing_points (nothing reads the beam layer here)
+                        // agent.py:166-168 hit('F'): the last-index agent (:603) on a cell where a ray stopped loses 50 per ray
+                        uint64_t hits = ballot(stopper & (kk == fs) & (fs < ff));
+                        const bool top = __builtin_amdgcn_inverse_ballot_w64(highest);
+                        for (; hits; hits &= hits - 1) {
+                            const uint32_t hit_cell = rl((uint32_t)cidx, (uint32_t)__builtin_ctzll(hits));
+                            rew -= (top & (cell == hit_cell)) ? 50 : 0;
+                        }
+                    }
+                    wave_sync();
+                }
+                for (int k = 0; GAME == 1 && shooters && k < nord; ++k) {
+                    const uint32_t a = rl(ordv, k);
+                    if (!((shooters >> a) & 1)) continue;
+                    shooters &= ~bit(a);
+                    const int aa = (int)rl((uint32_t)act, a);
+                    const bool fire = aa == kFire, clean = !fire;                       // harvest.py:62-67, cleanup.py:94-111
+                    if (fire && lane == (int)a) rew -= 1;                               // agent.py:170-172 fire_beam('F')
+                    // update_map_fire (map_env.py:566-649): lane = (ray q, step kk)
+                    const int pc = (int)rl(cell, a);
+                    int dr, dc;
+                    unit_vec((int)rl(orient, a), dr, dc);
+                    const int dlin = dr * WP + dc, rlin = -dc * WP + dr;                // d and rotate_right(d) = (-dc, dr) (:607) as cell offsets
+                    const int q = (lane >= L) + (lane >= 2 * L), kk = lane - q * L;
+                    const bool inray = lane < 3 * L;
+                    // :608-609 rays start at pos, pos + right - d, pos - right - d; ray cell kk is start + (kk + 1) * d.
+                    // The map's border is wall (ssd_create / ssd_set_state insist) and a ray ends at the first '@'
+                    // (:616), so the in-bounds test of :615 can never be what stops it: cells past the wall are
+                    // read (harmlessly, possibly outside the grid) and ignored by the first-stop logic below.
+                    const int cidx = inray ? pc + (q == 1 ? rlin : q == 2 ? -rlin : 0) + dlin * (kk + (q == 0)) : pc;
+                    const uint8_t wch = s_world[cidx], och = s_occ[cidx];
+                    const bool pass = inray & (wch != '@');                             // :616
+                    const bool stopper = pass & ((och != 0) | (clean & (wch == 'H')));  // :621 agents absorb, :639 blocking cell
+                    const uint64_t mf = ballot(inray & !pass), ms = ballot(stopper);
+                    const uint32_t f = (uint32_t)(mf >> (q * L)) & rmask, s = (uint32_t)(ms >> (q * L)) & rmask;
+                    const int ff = f ? __builtin_ctz(f) : L, fs = s ? __builtin_ctz(s) : L;
+                    const int len = fs < ff ? fs + 1 : ff;                              // beam covers the stopping cell
+                    wave_sync();
+                    if (inray && kk < len) {
+                        s_beam[cidx] = clean ? 'C' : 'F';                               // :624,:636 firing_points
+                        if (clean && wch == 'H') s_world[cidx] = 'R';                   // :625-634 cell_types ['H'] -> ['R']
+                    }
+                    if (fire) {                                                         // agent.py:166-168 hit('F'): -50
+                        for (int q2 = 0; q2 < 3; ++q2) {
+                            const uint32_t f2 = (uint32_t)(mf >> (q2 * L)) & rmask, s2 = (uint32_t)(ms >> (q2 * L)) & rmask;
+                            const int ff2 = f2 ? __builtin_ctz(f2) : L, fs2 = s2 ? __builtin_ctz(s2) : L;
+                            if (fs2 < ff2) {
+                                const uint32_t sl = (uint32_t)(q2 * L + fs2);
+                                if (rl((uint32_t)och, sl)) {                            // an agent (not waste) stopped the ray
+                                    const uint32_t hit_cell = rl((uint32_t)cidx, sl);
+                                    const uint64_t vm = ballot(is_agent && cell == hit_cell);
+                                    if (vm && lane == 63 - __builtin_clzll(vm)) rew -= 50;   // :603 last index wins
                                 }
                             }
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 3; ++q)
-                                if (q < ncell) { dstf[q * 3] = f[q * 3]; dstf[q * 3 + 1] = f[q * 3 + 1]; dstf[q * 3 + 2] = f[q * 3 + 2]; }
                         }
-                        continue;
                     }
-                    uint8_t *dst = out_env + (size_t)ag * VV * 3 + off3;
-                    if (VV >= 4) {
-                        if (lane_on) {
-                            typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-                            struct __attribute__((packed, aligned(1))) P3 { u32x3 v; };
-                            u32x3 d;
-                            // 4 x (r,g,b) -> 12 bytes with three byte permutes (v_perm_b32: selector bytes 0-3 pick from
-                            // the second operand, 4-7 from the first)
-                            d.x = __builtin_amdgcn_perm(px[1], px[0], 0x04020100u);   // r0 g0 b0 r1
-                            d.y = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);   // g1 b1 r2 g2
-                            d.z = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);   // b2 r3 g3 b3
-                            reinterpret_cast<P3 *>(dst)->v = d;
+                    wave_sync();                                                        // :551-552 updates land before the next shooter
+                }
+            }
+
+            SSD_STAMP(4);   // beams
+            if (mode != kModeObserve) {
+                // ---- custom_map_update (map_env.py:187 / :230): respawn ----
+                // Lanes walk the map's static apple-point list (row-major, as the reference iterates it).  A list entry is
+                // grid index | dense index << 16: the grid index addresses the padded-row layers, the dense index
+                // (row * W + col, what prng.py keys the per-cell draws with) feeds the PRNG.
+                // The LDS reads of one list entry are unconditional (padding entries point at an interior
+                // cell), so they go out as one independent batch.
+                uint64_t spawn_bits = 0;                                                // bit j: list entry lane + 64*j gets an apple
+                const uint32_t pk_apple = phase_key(key, t, kApple);
+                const int a_iters = (p.n_apple + 63) >> 6;
+                const uint32_t safe = (uint32_t)(WP + 1);                               // cell (1,1)
+                uint32_t waste_cell = 0xFFFFFFFFu;
+                uint32_t waste_count = 0;                                               // #'H' the probabilities were computed from
+                if (!SSD_SKIP(3)) {
+                if (GAME == 0) {
+                    // harvest.py:75-104 spawn_apples.  Apple points are interior cells (the border is wall),
+                    // so the 3x3 neighbourhood (j*j + k*k <= 2 on the radius-2 box, :90-92) is always in bounds.
+                    // Threshold by neighbour count as a sum of steps on n >= k.  (An `n == 0 ? a : n == 1 ? b : ...`
+                    // chain is turned into a switch lookup table by the compiler: an indexed vector load from the
+                    // kernarg buffer in memory -- an L2 round trip per list entry on the critical path.)
+                    const uint32_t t0 = p.thr_h32[0], d1 = p.thr_h32[1] - t0, d2 = p.thr_h32[2] - p.thr_h32[1],
+                                   d3 = p.thr_h32[3] - p.thr_h32[2];
+                    // 3x3 apple count, threshold and keyed draw of one candidate cell (:90-103)
+                    auto wins = [&](uint32_t ce) -> bool {
+                        const int c = (int)(ce & 0xFFFFu);
+                        uint32_t n = 0;
+    #pragma unroll
+                        for (int dr = -1; dr <= 1; ++dr)
+    #pragma unroll
+                            for (int dc = -1; dc <= 1; ++dc)
+                                if (dr != 0 || dc != 0) n += s_world[c + dr * WP + dc] == 'A';
+                        const uint32_t thr = t0 + (n >= 1 ? d1 : 0u) + (n >= 2 ? d2 : 0u) + (n >= 3 ? d3 : 0u);   // SPAWN_PROB[min(n, 3)]
+                        const bool always = ((p.thr_h_always >> (n < 3 ? n : 3u)) & 1u) != 0;
+                        return (draw(pk_apple, ce >> 16) < thr) | always;
+                    };
+                    // Pass 1 (cheap): which list entries are candidates at all -- an empty cell nobody stands on (:88).
+                    bool el[kListRegs];
+                    uint64_t em[kListRegs];
+                    int total = 0;
+    #pragma unroll
+                    for (int j = 0; j < kListRegs; ++j) {
+                        const bool valid = lane + 64 * j < p.n_apple;
+                        const uint32_t c = (valid ? alist[j] : safe) & 0xFFFFu;
+                        el[j] = valid & (s_world[c] != 'A') & (s_occ[c] == 0);
+                        em[j] = ballot(el[j]);
+                        total += __builtin_popcountll(em[j]);
+                    }
+                    if (a_iters <= kListRegs && total <= 64) {
+                        // Usual case: at most 64 candidates among the (up to 192) apple points.  Compact them through
+                        // 128 B of LDS scratch so that ONE pass of lanes does the stencil + draw instead of three.
+                        if (total) {
+                            int base = 0;
+    #pragma unroll
+                            for (int j = 0; j < kListRegs; ++j) {
+                                const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(em[j] >> 32),
+                                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)em[j], 0u));
+                                if (el[j]) s_tmp[slot] = alist[j];
+                                base += __builtin_popcountll(em[j]);
+                            }
+                            wave_sync();
+                            const bool mine = lane < total;
+                            const uint32_t c = mine ? s_tmp[lane] : safe;
+                            const bool hit = mine & wins(c);
+                            wave_sync();                                                // every count used the pre-spawn map (:73)
+                            if (hit) s_world[c & 0xFFFFu] = 'A';
                         }
                     } else {
-#pragma unroll
-                        for (int q = 0; q < 3; ++q)
-                            if (q < ncell) {
-                                dst[q * 3 + 0] = (uint8_t)px[q];
-                                dst[q * 3 + 1] = (uint8_t)(px[q] >> 8);
-                                dst[q * 3 + 2] = (uint8_t)(px[q] >> 16);
+                        // general form: every lane evaluates its own list entries
+    #pragma unroll
+                        for (int j = 0; j < kListRegs; ++j) {
+                            const uint32_t c = el[j] ? alist[j] : safe;
+                            spawn_bits |= (el[j] & wins(c)) ? bit(j) : 0ull;
+                        }
+                        for (int j = kListRegs; j < a_iters; ++j) {
+                            const int idx = lane + 64 * j;
+                            const bool valid = idx < p.n_apple;
+                            const uint32_t c = valid ? p.apple_cells[idx] : safe;
+                            const bool cand = valid & (s_world[c & 0xFFFFu] != 'A') & (s_occ[c & 0xFFFFu] == 0);
+                            spawn_bits |= (cand & wins(c)) ? bit(j) : 0ull;
+                        }
+                    }
+                } else {
+                    // cleanup.py:113-116: compute_probabilities (:156-171) from the current waste count, then
+                    // spawn_apples_and_waste (:132-154).  Thresholds come from a host-computed table.
+                    uint32_t nh = 0;
+                    for (int i = lane * 16; i < S; i += 64 * 16) {
+                        const uint4 qd = *reinterpret_cast<const uint4 *>(s_world + i);
+                        nh += count_bytes_eq(qd.x, 'H') + count_bytes_eq(qd.y, 'H') + count_bytes_eq(qd.z, 'H') + count_bytes_eq(qd.w, 'H');
+                    }
+                    nh = wave_sum_u32(nh);                                              // compute_permitted_area (:173-179)
+                    waste_count = nh;
+                    nh = nh < (uint32_t)p.n_thr ? nh : (uint32_t)p.n_thr - 1;
+                    const uint64_t thr_a = p.thr_ca[nh], thr_w = p.thr_cw[nh];
+                    auto apple = [&](int j, uint32_t c, bool valid) {                   // :135-141
+                        c = valid ? c : safe;
+                        const uint8_t w = s_world[c & 0xFFFFu], o = s_occ[c & 0xFFFFu];
+                        const bool hit = valid & (w != 'A') & (o == 0) & ((uint64_t)draw(pk_apple, c >> 16) < thr_a);
+                        spawn_bits |= hit ? bit(j) : 0ull;
+                    };
+    #pragma unroll
+                    for (int j = 0; j < kListRegs; ++j) apple(j, alist[j], lane + 64 * j < p.n_apple);
+                    for (int j = kListRegs; j < a_iters; ++j) {
+                        const int idx = lane + 64 * j;
+                        apple(j, idx < p.n_apple ? p.apple_cells[idx] : 0u, idx < p.n_apple);
+                    }
+                    if (thr_w) {
+                        // :144-153 shuffled scan, first non-'H' point whose coin succeeds (at most one per step):
+                        // order = ascending (ORDER draw, cell), coin keyed by cell.
+                        const uint32_t pk_coin = phase_key(key, t, kWasteCoin), pk_ord = phase_key(key, t, kWasteOrder);
+                        bool has = false;
+                        uint32_t bh = 0, bl = 0;
+                        auto waste = [&](uint32_t ce, bool valid) {
+                            ce = valid ? ce : safe;
+                            const uint32_t c = ce & 0xFFFFu;                             // ties break on the cell: grid and dense order agree
+                            const bool cand = valid & (s_world[c] != 'H') & ((uint64_t)draw(pk_coin, ce >> 16) < thr_w);
+                            const uint32_t kh = draw(pk_ord, ce >> 16);
+                            const bool better = cand & (!has | (kh < bh) | ((kh == bh) & (c < bl)));
+                            bh = better ? kh : bh; bl = better ? c : bl; has = has | cand;
+                        };
+                        const int w_iters = (p.n_waste + 63) >> 6;
+    #pragma unroll
+                        for (int j = 0; j < kListRegs; ++j) waste(wlist[j], lane + 64 * j < p.n_waste);
+                        for (int j = kListRegs; j < w_iters; ++j) {
+                            const int idx = lane + 64 * j;
+                            waste(idx < p.n_waste ? p.waste_cells[idx] : 0u, idx < p.n_waste);
+                        }
+                        uint32_t oh, ol;
+                        if (wave_argmin_pair(has, bh, bl, oh, ol)) waste_cell = ol;
+                    }
+                }
+                }
+                wave_sync();                                                            // counts use the pre-spawn map (harvest.py:73)
+    #pragma unroll
+                for (int j = 0; j < kListRegs; ++j)
+                    if ((spawn_bits >> j) & 1) s_world[alist[j] & 0xFFFFu] = 'A';
+                for (int j = kListRegs; j < a_iters; ++j)
+                    if ((spawn_bits >> j) & 1) s_world[p.apple_cells[lane + 64 * j] & 0xFFFFu] = 'A';
+                if (waste_cell != 0xFFFFFFFFu) s_world[waste_cell] = 'H';               // may land under an agent
+                wave_sync();
+
+                SSD_STAMP(5);   // respawn
+                // ---- write the env back (grid, agents, header: a rollout does that once, after its last step) and
+                //      this step's rewards and dones ----
+                waste_last = waste_count;
+                if (!roll) write_state();
+                if (is_agent && is_step) {
+                    if (p.rew) p.rew[slot_en + (size_t)e * N + lane] = rew;             // compute_reward (:208)
+                    // get_done -> False (:209); with a horizon set, the episode ends after `horizon` steps
+                    if (p.done) p.done[slot_en + (size_t)e * N + lane] = (p.horizon > 0 && t >= (uint32_t)p.horizon) ? 1 : 0;
+                }
+                wave_sync();
+            }
+
+            SSD_STAMP(6);   // write-back issued
+            // ---- get_map_with_agents (map_env.py:280-302): world <- agents <- beams, 4 cells per op (in place, except in a
+            //      rollout, whose world layer lives on) ----
+            if (!roll || is_step)
+            for (int i = lane * 4; i < S; i += 64 * 4) {
+                const uint32_t w = *reinterpret_cast<const uint32_t *>(s_world + i);
+                const uint32_t o = *reinterpret_cast<const uint32_t *>(s_occ + i);
+                const uint32_t b = *reinterpret_cast<const uint32_t *>(s_beam + i);
+                const uint32_t mo = nonzero_bytes(o), mb = nonzero_bytes(b);
+                uint32_t v = (w & ~mo) | (o & mo);
+                v = (v & ~mb) | (b & mb);
+                *reinterpret_cast<uint32_t *>(s_view + i) = v;
+            }
+            wave_sync();
+            SSD_STAMP(7);   // overlay built
+            SSD_STAMP(8);
+
+            // ---- per-agent observations (agent.py:76-78 -> utility_funcs.py:59-114 window with '0' padding,
+            //      map_env.py:316-339 colour LUT, :669-689 rotate_view).  The wave renders its own env's agents
+            //      one after the other: lane = 4 consecutive cells of the V x V view (12 contiguous output
+            //      bytes), so the view coordinates are per-lane constants, the agent's position and rotation
+            //      are scalars, and one wave store covers up to 768 contiguous bytes of the uint8 obs tensor.
+            //      Thanks to the padded grid layout a view cell is ONE multiply-add away from its LDS address.
+            //      An agent's block starts at a multiple of V*V*3 = 675 bytes, i.e. at any byte alignment:
+            //      the 12-byte stores rely on gfx9's unaligned global access. ----
+            if (p.obs && (!roll || is_step)) {
+                typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+                const int V = STD ? 15 : p.V, v = STD ? 7 : p.view_len, VV = V * V;
+                // (diagnostic builds, skip bit 4: all envs write the first 64 envs' blocks -- same instructions, no HBM write stream)
+                uint8_t *out_env = p.obs + (slot_en + (size_t)(SSD_SKIP(4) ? (e & 63) : e) * N) * VV * 3;
+                // Per-agent constants, computed once with lane = agent and read back as scalars in the loop.
+                // Window cell (a, b) of an agent on grid cell `cell` is grid cell cell + (a - v) * WP + (b - v).
+                // The view is rot90^k of the window (rotate_view, map_env.py:669-689; UP 0, LEFT 1, DOWN 2,
+                // RIGHT 3; reset observations are not rotated): view cell (i, j) shows window cell
+                //   k=0 (i, j)   k=1 (j, V-1-i)   k=2 (V-1-i, V-1-j)   k=3 (V-1-j, i)
+                // i.e. with lin0 = i*WP + j, lin1 = j*WP + (V-1-i) and C = (V-1)*(WP+1):
+                //   address = base + lin0 | base + lin1 | base + C - lin0 | base + C - lin1,   base = cell - v*(WP+1).
+                uint32_t a_s0 = 0, a_k = 0;
+                if (is_agent) {
+                    a_k = (is_step || p.rotate) ? (orient == 2 ? 0u : orient == 0 ? 1u : orient == 3 ? 2u : 3u) : 0u;
+                    a_s0 = (uint32_t)((int)cell - v * (WP + 1) + (a_k >= 2 ? (V - 1) * (WP + 1) : 0));
+                }
+                const uint32_t world_lds = (uint32_t)(uintptr_t)(lds_u8 *)s_view;       // LDS byte address of grid cell 0
+                for (int base = 0; base < VV; base += 256) {
+                    // A lane renders 4 consecutive cells = one 12-byte store.  V*V is not a multiple of 4 (225 = 56*4 + 1):
+                    // the lane holding the leftover cells starts 4 cells before the end instead, re-rendering up to 3
+                    // cells of its neighbour (same bytes, written twice) so that EVERY store is a full 12 bytes and the
+                    // wave never takes a divergent byte-store path.  Views under 4 cells (view_len 0) use byte stores.
+                    const int pp_raw = base + 4 * lane;
+                    const bool lane_on = pp_raw < VV;
+                    const int pp0 = (VV >= 4 && pp_raw > VV - 4) ? VV - 4 : pp_raw;     // lanes past the end repeat the last one
+                    int L0[4], L1[4];
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int pp = pp0 + q;
+                        const int i = STD ? pp / 15 : (int)(((uint32_t)pp * p.v_magic16) >> 16), j = pp - i * V;   // pp / V, pp % V
+                        // 24-bit multiply-adds (full rate; a plain `*` becomes a quarter-rate 32-bit multiply here)
+                        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(L0[q]) : "v"(i), "s"(WP), "v"(j));
+                        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(L1[q]) : "v"(j), "s"(WP), "v"(V - 1 - i));
+                    }
+                    uint32_t off3 = (uint32_t)pp0 * 3u;                                 // byte offset of the lane's cells in an agent's block
+                    asm volatile("" : "+v"(off3));                                      // keep it in a register (else re-derived per agent)
+                    const int ncell = lane_on ? VV - pp0 : 0;                           // >= 4 whenever VV >= 4
+                    if (STD && NA > 0 && NA % 5 == 0 && !F32) {
+                        // Specialised kernels: five agents per pass.  All their grid reads go out together, then all the
+                        // colour-table reads, then the stores: two LDS round trips per pass instead of two per agent.
+                        constexpr int kB = 5;
+                        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                        struct __attribute__((packed, aligned(1))) P3 { u32x3 v; };
+                        for (int ag0 = 0; ag0 < NA; ag0 += kB) {
+                            uint32_t addr[kB][4], px[kB][4];
+    #pragma unroll
+                            for (int u = 0; u < kB; ++u) {
+                                const uint32_t k = rl(a_k, ag0 + u);
+                                const uint32_t s0 = rl(a_s0, ag0 + u) + world_lds;
+                                const int sgn = k >= 2 ? -1 : 1;
+                                if (k & 1) {
+    #pragma unroll
+                                    for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[u][q]) : "v"(L1[q]), "v"(sgn), "s"(s0));
+                                } else {
+    #pragma unroll
+                                    for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[u][q]) : "v"(L0[q]), "v"(sgn), "s"(s0));
+                                }
                             }
+                            uint32_t gl[kB][4];
+    #pragma unroll
+                            for (int u = 0; u < kB; ++u)
+    #pragma unroll
+                                for (int q = 0; q < 4; ++q) gl[u][q] = *(lds_u8 *)(uintptr_t)addr[u][q];
+    #pragma unroll
+                            for (int u = 0; u < kB; ++u)
+    #pragma unroll
+                                for (int q = 0; q < 4; ++q) px[u][q] = s_lut[gl[u][q]];
+                            if (lane_on) {
+    #pragma unroll
+                                for (int u = 0; u < kB; ++u) {
+                                    u32x3 d;
+                                    d.x = __builtin_amdgcn_perm(px[u][1], px[u][0], 0x04020100u);   // r0 g0 b0 r1
+                                    d.y = __builtin_amdgcn_perm(px[u][2], px[u][1], 0x05040201u);   // g1 b1 r2 g2
+                                    d.z = __builtin_amdgcn_perm(px[u][3], px[u][2], 0x06050402u);   // b2 r3 g3 b3
+                                    reinterpret_cast<P3 *>(out_env + (size_t)(ag0 + u) * VV * 3 + off3)->v = d;
+                                }
+                            }
+                        }
+                    } else
+                    for (int ag = 0; ag < N; ++ag) {
+                        const uint32_t k = rl(a_k, ag);
+                        const uint32_t s0 = rl(a_s0, ag) + world_lds;
+                        const int sgn = k >= 2 ? -1 : 1;                                // one VGPR per agent: v_mad takes one scalar operand
+                        uint32_t addr[4], px[4];
+                        // wave-uniform branch on the rotation's parity instead of a per-cell select (the asm is volatile so
+                        // that the two arms are not merged back into selects)
+                        if (k & 1) {
+    #pragma unroll
+                            for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[q]) : "v"(L1[q]), "v"(sgn), "s"(s0));
+                        } else {
+    #pragma unroll
+                            for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[q]) : "v"(L0[q]), "v"(sgn), "s"(s0));
+                        }
+                        // a cell outside the map reads the '0' of the row padding / aprons (utility_funcs.py:94-114)
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) px[q] = s_lut[*(lds_u8 *)(uintptr_t)addr[q]];
+                        const size_t cell0 = (size_t)ag * VV + pp0;                     // first of this lane's cells within the env
+                        if (obs_f32) {
+                            // float32 mode: 3 floats per cell through the exact byte -> float table, 48 contiguous
+                            // bytes per lane (three 16-byte stores; an agent block starts at a multiple of 2700 B)
+                            float *dstf = reinterpret_cast<float *>(p.obs) + ((slot_en + (size_t)e * N) * VV + cell0) * 3;
+                            float f[12];
+    #pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                f[q * 3 + 0] = s_f32[px[q] & 0xFFu];
+                                f[q * 3 + 1] = s_f32[(px[q] >> 8) & 0xFFu];
+                                f[q * 3 + 2] = s_f32[(px[q] >> 16) & 0xFFu];
+                            }
+                            if (VV >= 4) {
+                                if (lane_on) {
+                                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                                    struct __attribute__((packed, aligned(4))) F4 { f32x4 v; };
+    #pragma unroll
+                                    for (int k4 = 0; k4 < 3; ++k4) {
+                                        f32x4 v4 = {f[4 * k4], f[4 * k4 + 1], f[4 * k4 + 2], f[4 * k4 + 3]};
+                                        reinterpret_cast<F4 *>(dstf + 4 * k4)->v = v4;
+                                    }
+                                }
+                            } else {
+    #pragma unroll
+                                for (int q = 0; q < 3; ++q)
+                                    if (q < ncell) { dstf[q * 3] = f[q * 3]; dstf[q * 3 + 1] = f[q * 3 + 1]; dstf[q * 3 + 2] = f[q * 3 + 2]; }
+                            }
+                            continue;
+                        }
+                        uint8_t *dst = out_env + (size_t)ag * VV * 3 + off3;
+                        if (VV >= 4) {
+                            if (lane_on) {
+                                typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                                struct __attribute__((packed, aligned(1))) P3 { u32x3 v; };
+                                u32x3 d;
+                                // 4 x (r,g,b) -> 12 bytes with three byte permutes (v_perm_b32: selector bytes 0-3 pick from
+                                // the second operand, 4-7 from the first)
+                                d.x = __builtin_amdgcn_perm(px[1], px[0], 0x04020100u);   // r0 g0 b0 r1
+                                d.y = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);   // g1 b1 r2 g2
+                                d.z = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);   // b2 r3 g3 b3
+                                reinterpret_cast<P3 *>(dst)->v = d;
+                            }
+                        } else {
+    #pragma unroll
+                            for (int q = 0; q < 3; ++q)
+                                if (q < ncell) {
+                                    dst[q * 3 + 0] = (uint8_t)px[q];
+                                    dst[q * 3 + 1] = (uint8_t)(px[q] >> 8);
+                                    dst[q * 3 + 2] = (uint8_t)(px[q] >> 16);
+                                }
+                        }
                     }
                 }
             }
+            if (!roll) break;
+            if (in_reset) { in_reset = false; continue; }     // the step this reset was due before comes next
+            if (++k_step >= p.n_steps) break;
+            slot = slot + 1 == (uint32_t)p.ring ? 0u : slot + 1;
+            if (to_reset >= 0) to_reset = (to_reset == 0 ? p.reset_every : to_reset) - 1;
+            in_reset = to_reset == 0;
         }
+        if (roll) write_state();
     }
     SSD_STAMP(9);       // observations issued
     SSD_STAMP_RT(11);
@@ -999,12 +1048,16 @@ __global__ void ssd_render_full_kernel(const Params p, int e, uint8_t *rgb) {
 
 template <int GAME, bool F32, int NA, bool STD, bool FAST>
 static void launch_step(const Params &p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-    hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStep, F32, NA, STD, FAST>), grid, block, lds, s, p);
+    if (p.mode == kModeRollout) {
+        if constexpr (!F32) hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeRollout, false, NA, STD, FAST>), grid, block, lds, s, p);
+    } else {
+        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStep, F32, NA, STD, FAST>), grid, block, lds, s, p);
+    }
 }
 
 template <int GAME, bool F32>
 static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-    if (p.mode == kModeStep) {
+    if (p.mode == kModeStep || p.mode == kModeRollout) {
         // specialised step kernels for the reference's configurations (view 7, beam 5; 5 or 10 agents), and
         // among those the FAST ones for the game's shipped map called in the plain way
         const bool std_view = p.view_len == 7 && p.beam_len == 5;

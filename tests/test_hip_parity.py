@@ -376,10 +376,11 @@ def test_float32_observation_mode_is_the_cast_of_the_reference_float64():
         assert torch.equal(fa[0][~mask.bool()], before[~mask.bool()])          # rows of envs that were not reset stay
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("game", [K.GAME_HARVEST, K.GAME_CLEANUP])
-def test_rollout_random_is_the_same_launches_as_step_by_step(game):
+def test_rollout_random_is_the_same_launches_as_step_by_step(game, fused):
     """ssd_rollout_random (one library call for a whole random-action rollout, rollout.py:58-70) against the oracle
-    stepped one call at a time: every ring slot holds the observations / rewards of its step, a reset happens every
+    stepped one call at a time (fused: the whole call is ONE kernel launch, envs resident in LDS): every ring slot holds the observations / rewards of its step, a reset happens every
     `reset_every` steps, and a second call continues where the first stopped (step0)."""
     import torch
     E, N, ring, every = 96, 5, 4, 7
@@ -394,9 +395,9 @@ def test_rollout_random_is_the_same_launches_as_step_by_step(game):
             ora.reset()
         _, o_obs, o_rew, _ = ora.step_random()
         want[k] = (o_obs, o_rew)
-    eng.rollout_random(10, obs, rew, done, reset_every=every, step0=0)
+    eng.rollout_random(10, obs, rew, done, reset_every=every, step0=0, fused=fused)
     eng.set_rollout_chains(3)                                   # three env ranges on streams of their own: same results
-    eng.rollout_random(13, obs, rew, done, reset_every=every, step0=10)
+    eng.rollout_random(13, obs, rew, done, reset_every=every, step0=10, fused=fused)
     got_obs, got_rew = obs.cpu().numpy(), rew.cpu().numpy()
     for k in range(23 - ring, 23):                              # the last `ring` steps are still in the ring
         np.testing.assert_array_equal(got_obs[k % ring], want[k][0], err_msg="obs of step %d" % k)

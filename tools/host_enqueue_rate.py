@@ -51,3 +51,13 @@ for n in (1000, 3000):
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         print("rollout_random(%d): host %.2f us/launch, total %.2f us/launch" % (n, (t1 - t0) * 1e6 / n, (t2 - t0) * 1e6 / n))
+
+# the fused rollout kernel: ONE launch for all n steps
+for n in (1000, 3000):
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.rollout_random(n, ro, rr, rd, reset_every=1000, fused=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print("rollout_random(%d, fused): %.2f us/step = %.2f G agent-steps/s" % (n, (t2 - t0) * 1e6 / n, 4096 * 5 * n / (t2 - t0) / 1e9))
