@@ -408,3 +408,51 @@ def test_rollout_random_is_the_same_launches_as_step_by_step(game, fused):
     assert not done.any().item() and eng.status() == 0
     with pytest.raises(ValueError):
         eng.rollout_random(1, obs[:, :1], rew, done)
+
+
+def _fused_vs_oracle(eng, ora, E, N, V, steps, every, ring):
+    import torch
+    obs = torch.zeros((ring, E, N, V, V, 3), dtype=torch.uint8, device="cuda")
+    rew = torch.zeros((ring, E, N), dtype=torch.int32, device="cuda")
+    done = torch.ones((ring, E, N), dtype=torch.uint8, device="cuda")
+    want = {}
+    for k in range(steps):
+        if k % every == 0:
+            ora.reset()
+        _, o_obs, o_rew, _ = ora.step_random()
+        want[k] = (o_obs, o_rew)
+    first = steps // 3
+    eng.rollout_random(first, obs, rew, done, reset_every=every, step0=0, fused=True)
+    eng.rollout_random(steps - first, obs, rew, done, reset_every=every, step0=first, fused=True)
+    got_obs, got_rew = obs.cpu().numpy(), rew.cpu().numpy()
+    for k in range(max(steps - ring, 0), steps):
+        np.testing.assert_array_equal(got_rew[k % ring], want[k][1], err_msg="rew of step %d" % k)
+        np.testing.assert_array_equal(got_obs[k % ring], want[k][0], err_msg="obs of step %d" % k)
+    a, b = eng.get_state(), ora.get_state()
+    for key in ("world", "pos", "orient", "episode", "t"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert not done.any().item() and eng.status() == 0
+
+
+@pytest.mark.parametrize("case", range(len(UNUSUAL)))
+def test_fused_rollout_on_unusual_configurations(case):
+    """The rollout kernel's general instantiations (any map, view, beam length, agent count; maps above 1024 cells)."""
+    game, H, W, E, N, v, L, steps = UNUSUAL[case]
+    rng = np.random.RandomState(100 + case)
+    amap = _random_map(rng, H, W, game, n_spawn=N + 3)
+    eng = VecEngine(game, amap, num_envs=E, num_agents=N, view_len=v, beam_len=L, seed=case, keep_beams=bool(case % 2))
+    ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), view_len=v, beam_len=L, seed=case)
+    _fused_vs_oracle(eng, ora, E, N, 2 * v + 1, steps, every=9, ring=2)
+
+
+@pytest.mark.parametrize("cfg", [(K.GAME_HARVEST, "default", 10, 37), (K.GAME_CLEANUP, "default", 10, 64), (K.GAME_HARVEST, "default", 7, 50),
+                                 (K.GAME_HARVEST, "25x38", 5, 33), (K.GAME_CLEANUP, "48x36", 10, 21), (K.GAME_CLEANUP, "default", 1, 40)])
+def test_fused_rollout_specialisations(cfg):
+    """Every specialisation of the rollout kernel: N = 5 / 10 / other, shipped and other maps, ragged env counts; a reset
+    falls on the first step, in the middle and on the last step of a call."""
+    game, which, N, E = cfg
+    amap = {"default": K.HARVEST_MAP if game == K.GAME_HARVEST else K.CLEANUP_MAP, "25x38": K.harvest_map_25x38(),
+            "48x36": K.cleanup_map_48x36()}[which]
+    eng = VecEngine(game, amap, num_envs=E, num_agents=N, seed=5)
+    ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), seed=5)
+    _fused_vs_oracle(eng, ora, E, N, 15, steps=31, every=10, ring=3)
