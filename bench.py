@@ -133,8 +133,7 @@ def main():
 
     run_steps(0, args.warmup)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    parallel.barrier(dist, local_rank)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -143,8 +142,7 @@ def main():
     ev1.record()
     enq = time.perf_counter() - t0                 # host time to enqueue the K steps (must stay below the device time)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    parallel.barrier(dist, local_rank)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
@@ -156,8 +154,7 @@ def main():
     if use_rollout and not args.obs_f32:
         eng.rollout_random(args.warmup, ring[0], ring[1], ring[2], reset_every=HORIZON, step0=0, fused=True)
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        parallel.barrier(dist, local_rank)
         f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         f0.record()
         eng.rollout_random(args.steps, ring[0], ring[1], ring[2], reset_every=HORIZON, step0=args.warmup, fused=True)

@@ -38,13 +38,25 @@ def init_process_group(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
-    kw = {}
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
-        kw["device_id"] = torch.device("cuda", local_rank)
+    # No `device_id=` here: binding the group to the device at creation (eager communicator init) makes every later
+    # hipLaunchKernel of the process about 3 us slower on this ROCm / PyTorch pair (tools/rccl_slowdown_probe2.py:
+    # 8.2 -> 13.8 us per 4096-env step), which a launch-bound rollout cannot afford.  Pass the device to the collectives
+    # instead (barrier(dist, local_rank) below).
     if not dist.is_initialized():
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return dist, rank, world, local_rank
+
+
+def barrier(dist, local_rank=None):
+    """dist.barrier() that tells RCCL which device this rank uses (no guessing, no warning); no-op without a group."""
+    if dist is None:
+        return
+    if dist.get_backend() == "nccl" and local_rank is not None:
+        dist.barrier(device_ids=[local_rank])
+    else:
+        dist.barrier()
 
 
 def make_sharded_engine(game, ascii_map, num_envs_total, num_agents, rank, world_size, local_rank=None, **kw):
