@@ -395,16 +395,6 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                     if (!((acting >> lane) & 1)) act = -1;       // agents absent from the action dict do nothing
                 }
 
-                // A launch lasts as long as its slowest wave.  How long a wave will take is known here: in Cleanup every
-                // beam costs ~0.5 us (they are traced one after the other), the conflict path of the moves ~1.5 us.  Waves
-                // with more work ahead issue ahead of the waves they share a SIMD with (which have slack); measured
-                // -0.5 us per 4096-env launch.  (Harvest traces all beams at once: no priority needed for them.)
-                if (GAME == 1) {
-                    constexpr int kFireAct = 7, kCleanAct = 8;
-                    const int ns = __builtin_popcountll(ballot(is_agent && (act == kFireAct || act == kCleanAct)));
-                    if (ns >= 2) __builtin_amdgcn_s_setprio(2);
-                    else if (ns == 1) __builtin_amdgcn_s_setprio(1);
-                }
                 // ---- update_moves (map_env.py:357-543) ----
                 const bool mover = !SSD_SKIP(0) && is_agent && act >= 0 && act <= 4;              // :383
                 if (is_agent && (act == 5 || act == 6)) orient = turn(act, orient);   // :390-392
@@ -588,17 +578,23 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 constexpr int kFire = 7, kClean = 8;
                 uint64_t shooters = SSD_SKIP(2) ? 0ull : ballot(is_agent && (act == kFire || (GAME == 1 && act == kClean)));
                 SSD_NOTE(13, __builtin_popcountll(shooters));
-                if (GAME == 0 && shooters) {
+                if (is_agent && act == kFire) rew -= 1;                                 // agent.py:170-172 fire_beam('F')
+                const int R = 3 * L, G = STD ? 4 : 64 / R;
+                if (shooters && (GAME == 0 || __builtin_popcountll(shooters) <= G)) {
                     // Harvest: a FIRE beam changes nothing another beam reads (no cell types, no blocking cells, harvest.py:62-67;
                     // 'F' marks and penalties commute), so the rays of up to 64 / 3L shooters are traced in ONE pass:
                     // lane = (shooter slot g, ray q, step kk).  A wave with three shooters costs what one shooter costs.
-                    const int R = 3 * L, G = STD ? 4 : 64 / R;
+                    // Cleanup: a CLEAN beam turns the 'H' that stops it into 'R' (cleanup.py:94-111), which a later CLEAN beam
+                    // would pass through, and 'F' / 'C' marks overwrite each other in action order -- but only where the beams
+                    // of two shooters cover the same cell.  So: trace them all at once against the unchanged map, let every
+                    // covered cell be claimed by its shooter's slot, and if any lane finds its cell claimed by another slot
+                    // (beams of two shooters overlap) undo the claims and trace the shooters one after the other instead.
+                    const uint64_t all_shooters = shooters;
                     const int g = STD ? lane / 15 : lane / R, r = lane - g * R;
                     const int q = (r >= L) + (r >= 2 * L), kk = r - q * L;
                     const int cq = q == 1 ? 1 : q == 2 ? -1 : 0, ck = kk + (q == 0);   // ray cell = pos + cq * right + ck * d (:608-609)
                     const int sh = g * R + q * L;                                       // first lane of this lane's ray
-                    if (is_agent && act == kFire) rew -= 1;                             // agent.py:170-172 fire_beam('F')
-                    const uint32_t packed_agent = cell | (orient << 16);
+                    const uint32_t packed_agent = cell | (orient << 16) | ((GAME == 1 && act == kClean) ? 1u << 20 : 0u);
                     while (shooters) {
                         int a = -1, taken = 0;                                          // slot g <- the g-th remaining shooter
                         for (; taken < G && shooters; ++taken) {
@@ -609,7 +605,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                         const bool inray = a >= 0;
                         const uint32_t ar = (uint32_t)__builtin_amdgcn_ds_bpermute((inray ? a : 0) << 2, (int)packed_agent);
                         const int pc = (int)(ar & 0xFFFFu);
-                        const uint32_t o8 = (ar >> 16) << 3;                            // orientation code * 8: LEFT RIGHT UP DOWN
+                        const bool clean = GAME == 1 && ((ar >> 20) & 1u) != 0;         // CLEAN beam (cleanup.py:94-111), else FIRE
+                        const uint32_t o8 = ((ar >> 16) & 3u) << 3;                     // orientation code * 8: LEFT RIGHT UP DOWN
                         int dlin, rlin;                                                 // d and rotate_right(d) = (-dc, dr) (:607) as cell offsets
                         if (FAST) {
                             const uint32_t b = (uint32_t)WP & 0xFFu, nb = (uint32_t)(-WP) & 0xFFu;
@@ -624,14 +621,29 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                         const int cidx = inray ? pc + __mul24(rlin, cq) + __mul24(dlin, ck) : WP + 1;
                         const uint8_t wch = s_world[cidx], och = s_occ[cidx];
                         const bool pass = inray & (wch != '@');                         // :616
-                        const bool stopper = pass & (och != 0);                         // :621 agents absorb the beam
+                        const bool stopper = pass & ((och != 0) | (clean & (wch == 'H')));   // :621 agents absorb, :639 blocking cell
                         const uint64_t mf = ballot(inray & !pass), ms = ballot(stopper);
                         const uint32_t f = (uint32_t)(mf >> sh) & rmask, st = (uint32_t)(ms >> sh) & rmask;
                         const int ff = f ? __builtin_ctz(f) : L, fs = st ? __builtin_ctz(st) : L;
                         const int len = fs < ff ? fs + 1 : ff;                          // beam covers the stopping cell
-                        if (inray && kk < len) s_beam[cidx] = 'F';                      // :624 firing_points (nothing reads the beam layer here)
-                        // agent.py:166-168 hit('F'): the last-index agent (:603) on a cell where a ray stopped loses 50 per ray
-                        uint64_t hits = ballot(stopper & (kk == fs) & (fs < ff));
+                        const bool covered = inray & (kk < len);
+                        if (GAME == 1 && (all_shooters & (all_shooters - 1))) {         // two or more shooters
+                            if (covered) s_beam[cidx] = (uint8_t)(g + 1);               // claim (the beam layer is empty at this point)
+                            wave_sync();
+                            const uint8_t claimed = s_beam[cidx];
+                            if (ballot(covered & (claimed != (uint8_t)(g + 1)))) {      // two shooters' beams share a cell
+                                if (covered) s_beam[cidx] = 0;
+                                wave_sync();
+                                shooters = all_shooters;                                // -> one after the other, below
+                                break;
+                            }
+                        }
+                        if (covered) {
+                            s_beam[cidx] = clean ? 'C' : 'F';                           // :624,:636 firing_points
+                            if (clean && wch == 'H') s_world[cidx] = 'R';               // :625-634 cell_types ['H'] -> ['R']
+                        }
+                        // agent.py:166-168 hit('F'): the last-index agent (:603) on a cell where a FIRE ray stopped loses 50 per ray
+                        uint64_t hits = ballot(stopper & !clean & (och != 0) & (kk == fs) & (fs < ff));
                         const bool top = __builtin_amdgcn_inverse_ballot_w64(highest);
                         for (; hits; hits &= hits - 1) {
                             const uint32_t hit_cell = rl((uint32_t)cidx, (uint32_t)__builtin_ctzll(hits));
@@ -646,7 +658,6 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                     shooters &= ~bit(a);
                     const int aa = (int)rl((uint32_t)act, a);
                     const bool fire = aa == kFire, clean = !fire;                       // harvest.py:62-67, cleanup.py:94-111
-                    if (fire && lane == (int)a) rew -= 1;                               // agent.py:170-172 fire_beam('F')
                     // update_map_fire (map_env.py:566-649): lane = (ray q, step kk)
                     const int pc = (int)rl(cell, a);
                     int dr, dc;

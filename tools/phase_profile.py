@@ -38,9 +38,16 @@ def main():
     eq = torch.zeros(5, dtype=torch.float64)
     reps = 50
     burst = int(os.environ.get("SSD_PROFILE_BURST", "20"))     # launches back to back; the stamps are the last one's
+    chains = int(os.environ.get("SSD_PROFILE_CHAINS", "0"))   # > 0: the burst goes through ssd_rollout_random with that many chains
+    ring = tuple(t.unsqueeze(0) for t in out)
+    if chains:
+        eng.set_rollout_chains(chains)
     for _ in range(reps):
-        for _ in range(burst):
-            eng.step_random(out=out)
+        if chains:
+            eng.rollout_random(burst, *ring)
+        else:
+            for _ in range(burst):
+                eng.step_random(out=out)
         torch.cuda.synchronize()
         s = stamps.cpu().double()
         d = s[:, 1:10] - s[:, 0:9]
@@ -69,6 +76,11 @@ def main():
     for name, sel in (("fastest 10 %", idx[: E // 10]), ("middle 10 %", idx[E // 2 - E // 20: E // 2 + E // 20]), ("slowest 1 %", idx[-max(E // 100, 1):])):
         print("    %-13s phases (cycles): " % name + " ".join("%s %.0f" % (n.split()[0], v) for n, v in zip(NAMES, d_last[sel].mean(dim=0).tolist()) if n != "wg barrier")
               + " | starts %.2f us" % float(starts[sel].mean()))
+    if chains:
+        for c in range(chains):
+            lo, hi = E * c // chains, E * (c + 1) // chains
+            print("    chain %d (envs %d..%d): waves start %.2f..%.2f us, end %.2f..%.2f us" % (
+                c, lo, hi - 1, float(starts[lo:hi].min()), float(starts[lo:hi].max()), float(ends[lo:hi].min()), float(ends[lo:hi].max())))
     # position of the wave among the waves of its SIMD: envs e, e+? share a SIMD -- unknown mapping; report by end rank instead
     print("    wave entry -> first stamp (kernel-argument fetch): mean %.2f us, max %.2f us" % (
         float(((s[:, 10] - s[:, 14]) * 0.01).mean()), float(((s[:, 10] - s[:, 14]) * 0.01).max())))
