@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Long-run parity soak (GPU box): E envs, T random-action steps with a reset every 1000 steps; every K steps the
 engine's full state (world, positions, orientations, counters) and the step's observations / rewards are compared
-with the C oracle's.  python tools/soak_parity.py [harvest|cleanup] [E] [T] [K]"""
+with the C oracle's.  python tools/soak_parity.py [harvest|cleanup] [E] [T] [K] [step|chains|fused]
+(step: one step_random call per step; chains: ssd_rollout_random with 2 chains between checkpoints; fused: the rollout
+kernel, one launch between checkpoints)"""
 import os
 import sys
 import time
@@ -22,19 +24,32 @@ def main():
     E = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     T = int(sys.argv[3]) if len(sys.argv) > 3 else 4000
     Kc = int(sys.argv[4]) if len(sys.argv) > 4 else 50
+    how = sys.argv[5] if len(sys.argv) > 5 else "step"
     amap = K.HARVEST_MAP if game == K.GAME_HARVEST else K.CLEANUP_MAP
     eng = VecEngine(game, amap, num_envs=E, num_agents=5, seed=2024)
     ora = pyoracle.Oracle(game, amap, E, 5, G.default_lut(), seed=2024)
     out = eng.alloc_outputs()
-    eng.reset(obs=out[0]); ora.reset()
+    ora.reset()
+    if len(sys.argv) <= 5 or sys.argv[5] == "step":       # (the rollout calls reset at step 0 themselves: reset_every)
+        eng.reset(obs=out[0])
     t0 = time.time()
     checks = 0
     rsum = 0
+    ring = tuple(t.unsqueeze(0) for t in out)
+    if how != "step":
+        assert 1000 % Kc == 0
+        eng.set_rollout_chains(2 if how == "chains" else 1)
     for s in range(T):
         if s and s % 1000 == 0:
-            eng.reset(obs=out[0]); ora.reset()
-        obs, rew, _ = eng.step_random(out=out)
+            ora.reset()
+            if how == "step":
+                eng.reset(obs=out[0])
         want_obs = (s % Kc == Kc - 1)
+        if how == "step":
+            obs, rew, _ = eng.step_random(out=out)
+        elif s % Kc == 0:                                      # the Kc steps up to the next checkpoint in one library call
+            eng.rollout_random(Kc, *ring, reset_every=1000, step0=s, fused=(how == "fused"))
+            obs, rew = out[0], out[1]
         _, o_obs, o_rew, _ = ora.step_random(want_obs=want_obs)
         if want_obs:
             r = rew.cpu().numpy()
@@ -48,8 +63,8 @@ def main():
             if checks % 10 == 0:
                 print("step %6d ok (%d checkpoints, %.0f s)" % (s + 1, checks, time.time() - t0), flush=True)
     assert eng.status() == 0
-    print("soak ok: %s, %d envs x %d steps = %.1f M env-steps, %d checkpoints bit-exact" %
-          ("cleanup" if game else "harvest", E, T, E * T / 1e6, checks))
+    print("soak ok (%s): %s, %d envs x %d steps = %.1f M env-steps, %d checkpoints bit-exact" %
+          (how, "cleanup" if game else "harvest", E, T, E * T / 1e6, checks))
 
 
 if __name__ == "__main__":
