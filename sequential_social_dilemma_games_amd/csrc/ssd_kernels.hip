@@ -229,6 +229,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
     // needs one.  Pin what the prologue needs into SGPRs here so that the loads go out as one batch.
     asm volatile("" ::"s"(p.hdr), "s"(p.agents), "s"(p.world), "s"(p.lut), "s"(p.apple_cells), "s"(p.obs),
                  "s"(p.actions), "s"(p.order), "s"(p.n_apple), "s"(p.num_actions_random));
+    if (GAME == 1) asm volatile("" ::"s"(p.waste_cells), "s"(p.n_waste), "s"(p.thr_ca), "s"(p.thr_cw), "s"(p.n_thr));
+    else asm volatile("" ::"s"(p.thr_h32[0]), "s"(p.thr_h32[1]), "s"(p.thr_h32[2]), "s"(p.thr_h32[3]), "s"(p.thr_h_always));
     const int e = p.e_begin + blockIdx.x * (int)(blockDim.x >> 6) + wv;
     constexpr int mode = MODE;                               // compile-time: step / reset / observe
     bool active = e < p.E;                                   // wave-uniform
@@ -373,11 +375,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
             if (is_step) {
                 t += 1;
                 // ---- actions (map_env.py:171-173) ----
-                if (p.num_actions_random > 0) {                  // rollout.py:64-65 uniform random actions
+                if (roll || p.num_actions_random > 0) {          // rollout.py:64-65 uniform random actions (a rollout launch: always)
                     const uint32_t pk = phase_key(key, t, kAction);
                     if (is_agent) {
                         act = (int)randint(draw(pk, (uint32_t)lane), (uint32_t)p.num_actions_random);
-                        if (p.actions_out) p.actions_out[(size_t)e * N + lane] = act;
+                        if (!roll && p.actions_out) p.actions_out[(size_t)e * N + lane] = act;
                     }
                 } else {
                     act = act_in;
