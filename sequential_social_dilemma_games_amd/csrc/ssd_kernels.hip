@@ -729,24 +729,25 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                     auto wins = [&](uint32_t ce) -> bool {
                         const int c = (int)(ce & 0xFFFFu);
                         uint32_t n = 0;
-    #pragma unroll
+#pragma unroll
                         for (int dr = -1; dr <= 1; ++dr)
-    #pragma unroll
+#pragma unroll
                             for (int dc = -1; dc <= 1; ++dc)
                                 if (dr != 0 || dc != 0) n += s_world[c + dr * WP + dc] == 'A';
                         const uint32_t thr = t0 + (n >= 1 ? d1 : 0u) + (n >= 2 ? d2 : 0u) + (n >= 3 ? d3 : 0u);   // SPAWN_PROB[min(n, 3)]
                         const bool always = ((p.thr_h_always >> (n < 3 ? n : 3u)) & 1u) != 0;
                         return (draw(pk_apple, ce >> 16) < thr) | always;
                     };
-                    // Pass 1 (cheap): which list entries are candidates at all -- an empty cell nobody stands on (:88).
+                    // Pass 1 (cheap): which list entries are candidates at all -- a cell without an apple (:88; "nobody stands
+                    // on it" is checked for the few winners only).  The unused entries of the list registers are 0 = grid
+                    // cell 0, a wall, and an apple point is never a wall: "neither 'A' nor '@'" needs no validity test.
                     bool el[kListRegs];
                     uint64_t em[kListRegs];
                     int total = 0;
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < kListRegs; ++j) {
-                        const bool valid = lane + 64 * j < p.n_apple;
-                        const uint32_t c = (valid ? alist[j] : safe) & 0xFFFFu;
-                        el[j] = valid & (s_world[c] != 'A') & (s_occ[c] == 0);
+                        const uint8_t ch = s_world[alist[j] & 0xFFFFu];
+                        el[j] = (ch != 'A') & (ch != '@');
                         em[j] = ballot(el[j]);
                         total += __builtin_popcountll(em[j]);
                     }
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                         // 128 B of LDS scratch so that ONE pass of lanes does the stencil + draw instead of three.
                         if (total) {
                             int base = 0;
-    #pragma unroll
+#pragma unroll
                             for (int j = 0; j < kListRegs; ++j) {
                                 const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(em[j] >> 32),
                                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)em[j], 0u));
@@ -765,16 +766,16 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                             wave_sync();
                             const bool mine = lane < total;
                             const uint32_t c = mine ? s_tmp[lane] : safe;
-                            const bool hit = mine & wins(c);
+                            const bool hit = mine & wins(c) & (s_occ[c & 0xFFFFu] == 0);
                             wave_sync();                                                // every count used the pre-spawn map (:73)
                             if (hit) s_world[c & 0xFFFFu] = 'A';
                         }
                     } else {
                         // general form: every lane evaluates its own list entries
-    #pragma unroll
+#pragma unroll
                         for (int j = 0; j < kListRegs; ++j) {
                             const uint32_t c = el[j] ? alist[j] : safe;
-                            spawn_bits |= (el[j] & wins(c)) ? bit(j) : 0ull;
+                            spawn_bits |= (el[j] & wins(c) & (s_occ[c & 0xFFFFu] == 0)) ? bit(j) : 0ull;
                         }
                         for (int j = kListRegs; j < a_iters; ++j) {
                             const int idx = lane + 64 * j;
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                         const bool hit = valid & (w != 'A') & (o == 0) & ((uint64_t)draw(pk_apple, c >> 16) < thr_a);
                         spawn_bits |= hit ? bit(j) : 0ull;
                     };
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < kListRegs; ++j) apple(j, alist[j], lane + 64 * j < p.n_apple);
                     for (int j = kListRegs; j < a_iters; ++j) {
                         const int idx = lane + 64 * j;
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                             bh = better ? kh : bh; bl = better ? c : bl; has = has | cand;
                         };
                         const int w_iters = (p.n_waste + 63) >> 6;
-    #pragma unroll
+#pragma unroll
                         for (int j = 0; j < kListRegs; ++j) waste(wlist[j], lane + 64 * j < p.n_waste);
                         for (int j = kListRegs; j < w_iters; ++j) {
                             const int idx = lane + 64 * j;
@@ -835,7 +836,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 }
                 }
                 wave_sync();                                                            // counts use the pre-spawn map (harvest.py:73)
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < kListRegs; ++j)
                     if ((spawn_bits >> j) & 1) s_world[alist[j] & 0xFFFFu] = 'A';
                 for (int j = kListRegs; j < a_iters; ++j)
@@ -908,7 +909,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                     const bool lane_on = pp_raw < VV;
                     const int pp0 = (VV >= 4 && pp_raw > VV - 4) ? VV - 4 : pp_raw;     // lanes past the end repeat the last one
                     int L0[4], L1[4];
-    #pragma unroll
+#pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int pp = pp0 + q;
                         const int i = STD ? pp / 15 : (int)(((uint32_t)pp * p.v_magic16) >> 16), j = pp - i * V;   // pp / V, pp % V
@@ -927,30 +928,30 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                         struct __attribute__((packed, aligned(1))) P3 { u32x3 v; };
                         for (int ag0 = 0; ag0 < NA; ag0 += kB) {
                             uint32_t addr[kB][4], px[kB][4];
-    #pragma unroll
+#pragma unroll
                             for (int u = 0; u < kB; ++u) {
                                 const uint32_t k = rl(a_k, ag0 + u);
                                 const uint32_t s0 = rl(a_s0, ag0 + u) + world_lds;
                                 const int sgn = k >= 2 ? -1 : 1;
                                 if (k & 1) {
-    #pragma unroll
+#pragma unroll
                                     for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[u][q]) : "v"(L1[q]), "v"(sgn), "s"(s0));
                                 } else {
-    #pragma unroll
+#pragma unroll
                                     for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[u][q]) : "v"(L0[q]), "v"(sgn), "s"(s0));
                                 }
                             }
                             uint32_t gl[kB][4];
-    #pragma unroll
+#pragma unroll
                             for (int u = 0; u < kB; ++u)
-    #pragma unroll
+#pragma unroll
                                 for (int q = 0; q < 4; ++q) gl[u][q] = *(lds_u8 *)(uintptr_t)addr[u][q];
-    #pragma unroll
+#pragma unroll
                             for (int u = 0; u < kB; ++u)
-    #pragma unroll
+#pragma unroll
                                 for (int q = 0; q < 4; ++q) px[u][q] = s_lut[gl[u][q]];
                             if (lane_on) {
-    #pragma unroll
+#pragma unroll
                                 for (int u = 0; u < kB; ++u) {
                                     u32x3 d;
                                     d.x = __builtin_amdgcn_perm(px[u][1], px[u][0], 0x04020100u);   // r0 g0 b0 r1
@@ -969,14 +970,14 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                         // wave-uniform branch on the rotation's parity instead of a per-cell select (the asm is volatile so
                         // that the two arms are not merged back into selects)
                         if (k & 1) {
-    #pragma unroll
+#pragma unroll
                             for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[q]) : "v"(L1[q]), "v"(sgn), "s"(s0));
                         } else {
-    #pragma unroll
+#pragma unroll
                             for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[q]) : "v"(L0[q]), "v"(sgn), "s"(s0));
                         }
                         // a cell outside the map reads the '0' of the row padding / aprons (utility_funcs.py:94-114)
-    #pragma unroll
+#pragma unroll
                         for (int q = 0; q < 4; ++q) px[q] = s_lut[*(lds_u8 *)(uintptr_t)addr[q]];
                         const size_t cell0 = (size_t)ag * VV + pp0;                     // first of this lane's cells within the env
                         if (obs_f32) {
@@ -984,7 +985,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                             // bytes per lane (three 16-byte stores; an agent block starts at a multiple of 2700 B)
                             float *dstf = reinterpret_cast<float *>(p.obs) + ((slot_en + (size_t)e * N) * VV + cell0) * 3;
                             float f[12];
-    #pragma unroll
+#pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 f[q * 3 + 0] = s_f32[px[q] & 0xFFu];
                                 f[q * 3 + 1] = s_f32[(px[q] >> 8) & 0xFFu];
@@ -994,14 +995,14 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                                 if (lane_on) {
                                     typedef float f32x4 __attribute__((ext_vector_type(4)));
                                     struct __attribute__((packed, aligned(4))) F4 { f32x4 v; };
-    #pragma unroll
+#pragma unroll
                                     for (int k4 = 0; k4 < 3; ++k4) {
                                         f32x4 v4 = {f[4 * k4], f[4 * k4 + 1], f[4 * k4 + 2], f[4 * k4 + 3]};
                                         reinterpret_cast<F4 *>(dstf + 4 * k4)->v = v4;
                                     }
                                 }
                             } else {
-    #pragma unroll
+#pragma unroll
                                 for (int q = 0; q < 3; ++q)
                                     if (q < ncell) { dstf[q * 3] = f[q * 3]; dstf[q * 3 + 1] = f[q * 3 + 1]; dstf[q * 3 + 2] = f[q * 3 + 2]; }
                             }
@@ -1021,7 +1022,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                                 reinterpret_cast<P3 *>(dst)->v = d;
                             }
                         } else {
-    #pragma unroll
+#pragma unroll
                             for (int q = 0; q < 3; ++q)
                                 if (q < ncell) {
                                     dst[q * 3 + 0] = (uint8_t)px[q];
