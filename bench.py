@@ -188,7 +188,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "ssd::ssd_env_kernel<%d, 0, %s, ...>" % (game, "true" if args.obs_f32 else "false"), "bytes_per_env_step": bytes_env,
-                         "avg_launch_us": launch_us, "concurrent_launches": chains, "host_enqueue_us_per_step": enq * 1e6 / args.steps},
+                         "avg_launch_us": launch_us, "concurrent_launches": chains, "envs_per_launch": E // chains,
+                         "note": "achieved = algorithmic bytes per step (all concurrent launches) / time per step; each chain's launches "
+                                 "run back to back on its own stream, so time per step = launch-to-launch duration of the step kernel", "host_enqueue_us_per_step": enq * 1e6 / args.steps},
         }
         if fused_ms is not None:
             fus = fused_ms * 1e3 / args.steps
