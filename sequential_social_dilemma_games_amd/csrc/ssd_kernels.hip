@@ -1,25 +1,28 @@
 // csrc/ssd_kernels.hip -- the MapEnv.step() hot path as one fused gfx950 kernel.
 //
 // Mapping (CDNA4: 64-wide wavefronts, 160 KiB LDS per CU, 256 CUs):
-//   * one wavefront owns one env for the whole step; a 256-thread workgroup holds 4 envs;
-//   * the env's grid (16x38 = 608 B for Harvest) is pulled from HBM once with 16 B/lane loads
-//     into LDS, every phase works on the LDS copy, and it is written back once;
-//   * move / rotate / conflict resolution: lanes = agents, positions compared with wavefront
-//     ballots ("who stands on cell x" = ballot, last index = highest set bit), the order-dependent
-//     parts of the reference algorithm run as wave-uniform loops (map_env.py:357-543);
-//   * beams: lanes = (ray, step) pairs, stop positions from ballots (map_env.py:566-649);
+//   * one wavefront owns one env for the whole launch; a workgroup holds 1..16 envs (envs_per_block());
+//   * the env's grid (rows padded by view_len: 16 x (38 + 7) = 720 B for Harvest) is pulled from HBM once with
+//     16 B/lane loads into LDS, every phase works on the LDS copy, and it is written back once;
+//   * move / rotate / conflict resolution: lanes = agents, positions compared with wavefront ballots combined on
+//     the scalar unit ("who stands on cell x" = ballot, last index = highest set bit); the order-dependent parts
+//     of the reference algorithm run as wave-uniform code, chains of waiting agents by pointer jumping
+//     (map_env.py:357-543);
+//   * beams: lanes = (shooter, ray, step), stop positions from ballots (map_env.py:566-649);
 //   * respawn: lanes = entries of the map's static apple / waste cell lists (held in registers),
-//     3x3 stencil on the LDS grid, counter-based PRNG keyed on the cell
-//     (harvest.py:75-104, cleanup.py:132-171);
-//   * observation: the wave renders its env's N agents from the LDS overlay, lane = 4 consecutive
-//     cells of the 15 x 15 window = 12 contiguous bytes per store, so a wavefront store covers up to
-//     768 contiguous bytes of the uint8 obs tensor (map_env.py:189-199);
+//     3x3 stencil on the LDS grid, counter-based PRNG keyed on the cell (harvest.py:75-104, cleanup.py:132-171);
+//   * observation: the wave renders its env's N agents from the LDS overlay, lane = 4 consecutive cells of the
+//     15 x 15 view = 12 contiguous bytes per store, so a wavefront store covers up to 768 contiguous bytes of
+//     the uint8 obs tensor; the padded layout makes a view cell one multiply-add away from its LDS address
+//     (map_env.py:189-199);
 //   * waves never touch each other's LDS: the kernel has no workgroup barrier.
-// At 4096 envs (4 waves per SIMD) a launch lasts about as long as ONE wave's instruction stream plus
-// launch and store-drain time, so the code minimises a single wave's dynamic
-// instruction count and wait chain: every global load is issued in the prologue, cross-lane reductions
-// use DPP / scalar loops instead of LDS-crossbar shuffles, per-map work lists replace grid scans, and the
-// common conflict-free move takes a short path.
+// One source, four modes (template parameter): step, reset, observe -- one pass over the env per launch -- and
+// rollout, which loops [reset pass,] step pass, ... with the env resident in LDS / registers (SSD_ROLLOUT_FUSED).
+// At 4096 envs (4 waves per SIMD) a per-step launch lasts as long as its SLOWEST wave plus launch and store-drain
+// time, so the code minimises a single wave's dynamic instruction count and wait chain --
+// every global load is issued in the prologue, cross-lane reductions use DPP / scalar code instead of LDS-crossbar
+// shuffles, per-map work lists replace grid scans, the common conflict-free move takes a short path -- and lets
+// the rare long waves issue first (s_setprio).
 // No MFMA: the path is integer / indexing work; its roofline is HBM traffic (4 724 B per env-step).
 //
 // Reference citations are file:line of the reference repository (social_dilemmas/envs/...).
