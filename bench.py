@@ -100,31 +100,46 @@ def main():
     assert (start, count) == (rank * E, E)
     out = eng.alloc_outputs(float32=args.obs_f32)
     do_gather = bool(args.gather and dist is not None)
-    gbuf = None
-    if do_gather:                                  # the single batched tensors every rank ends up with
-        gbuf = (torch.empty((world * E,) + tuple(out[0].shape[1:]), dtype=torch.uint8, device=out[0].device),
-                torch.empty((world * E,) + tuple(out[1].shape[1:]), dtype=torch.int32, device=out[1].device))
+    GR = 8                                         # --gather: steps per collective (one RCCL all-gather moves GR steps' outputs)
+    gring = gbuf = None
+    if do_gather:                                  # the batched tensors every rank ends up with: [world, GR, E, ...]
+        gring = (torch.empty((GR,) + tuple(out[0].shape), dtype=out[0].dtype, device=out[0].device),
+                 torch.empty((GR,) + tuple(out[1].shape), dtype=torch.int32, device=out[1].device),
+                 torch.empty((GR,) + tuple(out[2].shape), dtype=torch.uint8, device=out[2].device))
+        gbuf = (torch.empty((world,) + tuple(gring[0].shape), dtype=gring[0].dtype, device=out[0].device),
+                torch.empty((world,) + tuple(gring[1].shape), dtype=torch.int32, device=out[1].device))
 
     def one_step(k):
         if k % HORIZON == 0:
             eng.reset(obs=out[0])
         eng.step_random(out=out)
-        if do_gather:                              # one batched tensor on every rank: RCCL all-gather over xGMI
-            parallel.all_gather_batch(dist, out[0], world * E, world, out=gbuf[0])
-            parallel.all_gather_batch(dist, out[1], world * E, world, out=gbuf[1])
 
     # Without --gather / --per-step-calls the steps are enqueued by ssd_rollout_random: the same launches (one step
     # kernel per step into the same output buffers, a full reset every HORIZON steps), issued by one library call per
     # chunk instead of one Python call per step, so that the host never starves the 9 us kernels.
     ring = tuple(t.unsqueeze(0) for t in out)
-    use_rollout = not (do_gather or args.per_step_calls)
+    use_rollout = not args.per_step_calls
     chains = 1
     if use_rollout:                                # env ranges the library steps on streams of its own (envs are independent)
         chains = args.chains if args.chains > 0 else (2 if E >= 2048 else 1)
         eng.set_rollout_chains(chains)
 
     def run_steps(k0, n):
-        if use_rollout:
+        if do_gather:
+            # GR steps into a ring of GR slots, then ONE RCCL all-gather of the ring (obs) and one of the rewards over xGMI:
+            # every rank ends up with all ranks' outputs of those steps
+            for c0 in range(k0, k0 + n, GR):
+                m = min(GR, k0 + n - c0)
+                if use_rollout:
+                    eng.rollout_random(m, gring[0], gring[1], gring[2], reset_every=HORIZON, step0=c0)
+                else:
+                    for k in range(c0, c0 + m):
+                        if k % HORIZON == 0:
+                            eng.reset(obs=gring[0][k % GR])
+                        eng.step_random(out=(gring[0][k % GR], gring[1][k % GR], gring[2][k % GR]))
+                parallel.all_gather_ring(dist, gring[0], world, out=gbuf[0])
+                parallel.all_gather_ring(dist, gring[1], world, out=gbuf[1])
+        elif use_rollout:
             for c0 in range(k0, k0 + n, 1000):
                 eng.rollout_random(min(1000, k0 + n - c0), ring[0], ring[1], ring[2], reset_every=HORIZON, step0=c0)
         else:
@@ -151,7 +166,7 @@ def main():
     # Reported separately and labelled: the same K steps as ONE fused kernel launch -- every env
     # resident in LDS / registers across its steps (SSD_ROLLOUT_FUSED).  Not part of `value`.
     fused_ms = None
-    if use_rollout and not args.obs_f32:
+    if use_rollout and not args.obs_f32 and not do_gather:
         eng.rollout_random(args.warmup, ring[0], ring[1], ring[2], reset_every=HORIZON, step0=0, fused=True)
         torch.cuda.synchronize()
         parallel.barrier(dist, local_rank)
@@ -184,7 +199,7 @@ def main():
             "config": {"workload": "%s %dx%d, %d agents, %d envs per GPU, uniform random actions, reset every %d steps"
                                    % (args.game, eng.H, eng.W, n_agents, E, HORIZON),
                        "envs_per_gpu": E, "agents": n_agents, "obs": ("float32" if args.obs_f32 else "uint8") + " [E,N,15,15,3]", "launches_per_step": chains, "enqueue": ("ssd_rollout_random, %d chain(s) of %d envs" % (chains, E // chains)) if use_rollout else "one call per step",
-                       "gather": do_gather, "parallelism": "env-shard x%d" % world},
+                       "gather": ("one RCCL all-gather of obs and one of rewards per %d steps" % GR) if do_gather else False, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "ssd::ssd_env_kernel<%d, 0, %s, ...>" % (game, "true" if args.obs_f32 else "false"), "bytes_per_env_step": bytes_env,

@@ -92,6 +92,21 @@ def all_gather_batch(dist, tensor, num_envs_total, world_size, out=None):
     return torch.cat([buf[r * mx:r * mx + counts[r]] for r in range(world_size)], dim=0)
 
 
+def all_gather_ring(dist, ring, world_size, out=None):
+    """One collective for several steps: `ring` is this rank's [R, count, ...] block of R steps' outputs (what
+    rollout_random() fills); every rank receives [world, R, count, ...] (rank-major: out[r, k] = step k of rank r's envs).
+    Fewer, larger RCCL all-gathers instead of one per step -- xGMI is per-link bound, so message size is what counts.
+    Equal shards only (the ragged case goes through all_gather_batch per step)."""
+    import torch
+    if dist is None:
+        return ring.unsqueeze(0)
+    if out is None:
+        out = torch.empty((world_size,) + tuple(ring.shape), dtype=ring.dtype, device=ring.device)
+    # (the output is the concatenation of the ranks' blocks along dim 0: hand it over in that shape)
+    dist.all_gather_into_tensor(out.view((world_size * ring.shape[0],) + tuple(ring.shape[1:])), ring.contiguous())
+    return out
+
+
 def gather_batch(dist, tensor, num_envs_total, world_size, rank, dst=0):
     """As all_gather_batch but only rank `dst` receives the batch (others get None): the root ingests
     the 7 peers' shards over its 7 direct xGMI links in parallel."""

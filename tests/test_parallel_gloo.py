@@ -54,6 +54,13 @@ def _worker(rank, world, port, total, game, n_agents, steps, q):
             out.append((full_obs.numpy().copy(), full_rew.numpy().copy()))
         else:
             assert full_rew is None and full_obs.shape[0] == total
+    if total % w == 0:                               # the multi-step form: one collective for a ring of R steps' outputs
+        ring = torch.stack([torch.full((count, 3), 100 * k + r, dtype=torch.int32) for k in range(4)])
+        got = parallel.all_gather_ring(dist, ring, w)
+        assert tuple(got.shape) == (w, 4, count, 3)
+        for rr in range(w):
+            for k in range(4):
+                assert (got[rr, k] == 100 * k + rr).all()
     dist.barrier()
     if r == 0:
         q.put(out)
