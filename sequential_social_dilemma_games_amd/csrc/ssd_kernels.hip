@@ -556,6 +556,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
 
             SSD_STAMP(2);   // moves resolved
             uint64_t highest = 0;                                // agents that are the highest index on their cell (agent_by_pos, :603)
+            // this step's beam cells, when one parallel pass traced them all: lane = (shooter, ray, step) -> covered cell, mark
+            bool beams_in_regs = true, b_cov = false;
+            int b_idx = 0;
+            uint32_t b_chr = 0;
             if (!is_reset && !SSD_SKIP(1)) {
                 // ---- consume (map_env.py:178-181, agent.py:177-183) + occupancy layer ----
                 // Index order means: of several agents on one cell the LOWEST index eats the apple, and
@@ -595,6 +599,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                     // covered cell be claimed by its shooter's slot, and if any lane finds its cell claimed by another slot
                     // (beams of two shooters overlap) undo the claims and trace the shooters one after the other instead.
                     const uint64_t all_shooters = shooters;
+                    beams_in_regs = __builtin_popcountll(all_shooters) <= G;            // one pass covers them all
                     const int g = STD ? lane / 15 : lane / R, r = lane - g * R;
                     const int q = (r >= L) + (r >= 2 * L), kk = r - q * L;
                     const int cq = q == 1 ? 1 : q == 2 ? -1 : 0, ck = kk + (q == 0);   // ray cell = pos + cq * right + ck * d (:608-609)
@@ -640,9 +645,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                                 if (covered) s_beam[cidx] = 0;
                                 wave_sync();
                                 shooters = all_shooters;                                // -> one after the other, below
+                                beams_in_regs = false;
                                 break;
                             }
                         }
+                        b_cov = covered; b_idx = cidx; b_chr = clean ? 'C' : 'F';
                         if (covered) {
                             s_beam[cidx] = clean ? 'C' : 'F';                           // :624,:636 firing_points
                             if (clean && wch == 'H') s_world[cidx] = 'R';               // :625-634 cell_types ['H'] -> ['R']
@@ -657,6 +664,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                     }
                     wave_sync();
                 }
+                if (GAME == 1 && shooters) beams_in_regs = false;
                 for (int k = 0; GAME == 1 && shooters && k < nord; ++k) {
                     const uint32_t a = rl(ordv, k);
                     if (!((shooters >> a) & 1)) continue;
@@ -861,9 +869,18 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
             }
 
             SSD_STAMP(6);   // write-back issued
-            // ---- get_map_with_agents (map_env.py:280-302): world <- agents <- beams, 4 cells per op (in place, except in a
-            //      rollout, whose world layer lives on) ----
-            if (!roll || is_step)
+            // ---- get_map_with_agents (map_env.py:280-302): world <- agents <- beams (in place, except in a rollout, whose
+            //      world layer lives on).  After a step whose beams one parallel pass traced, the cells that differ from the
+            //      world are in registers -- agents' cells, beam cells -- so two predicated byte stores do it (a rollout copies
+            //      the layer first, 16 B per lane); otherwise the three layers are merged 4 cells per op. ----
+            const bool patch = is_step && !keep_beams && beams_in_regs;
+            if (patch && !SSD_SKIP(5)) {
+                if (roll)
+                    for (int i = lane * 16; i < S; i += 64 * 16)
+                        *reinterpret_cast<uint4 *>(s_view + i) = *reinterpret_cast<const uint4 *>(s_world + i);
+                if (__builtin_amdgcn_inverse_ballot_w64(highest)) s_view[cell] = agent_glyph((uint32_t)lane);   // :289-297
+                if (b_cov) s_view[b_idx] = (uint8_t)b_chr;                                                      // :299-300, over the agents
+            } else if ((!roll || is_step) && !SSD_SKIP(5))   // (diagnostic builds: skip bit 5 = no overlay, to price it)
             for (int i = lane * 4; i < S; i += 64 * 4) {
                 const uint32_t w = *reinterpret_cast<const uint32_t *>(s_world + i);
                 const uint32_t o = *reinterpret_cast<const uint32_t *>(s_occ + i);

@@ -33,5 +33,7 @@ def t(label, obs=True):
 t("fused rollout")
 L.ssd_debug_set_skip(eng._h, 16)
 t("fused rollout, obs stores folded onto 64 envs' blocks (no write stream)")
+L.ssd_debug_set_skip(eng._h, 32)
+t("fused rollout, overlay phase skipped (wrong pixels; prices the overlay)")
 L.ssd_debug_set_skip(eng._h, 0)
 t("fused rollout, no observation output", obs=False)
