@@ -126,6 +126,21 @@ __device__ __forceinline__ void unit_vec(int code, int &dr, int &dc) {
     dc = code == 2 ? -1 : (code == 3 ? 1 : 0);
 }
 
+// Observation stores are write-through (sc1 = agent scope: the data leaves for HBM as it is produced).  With ordinary
+// stores the 13.8 MB of a 4096-env step sit dirty in L2 until the end-of-kernel write-back, which the next launch has to
+// wait for: 8.0 -> 6.9 us per step.  `base` is wave-uniform (SGPR pair), `off` the lane's byte offset; any alignment.
+// The s_nops are the gfx9 hazards the compiler cannot see through inline asm: a VMEM instruction must not read an SGPR
+// that a VALU instruction (v_readfirstlane) wrote less than 5 wait states earlier, and a VMEM store of more than 64 bits
+// reads its data registers late, so a VALU write to one of them needs wait states after the store.
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store12_wt(uint8_t *base, uint32_t off, u32x3_t d) {
+    asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+}
+__device__ __forceinline__ void store16_wt(float *base, uint32_t off, f32x4_t d) {
+    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+}
+
 // bytes of x that are non-zero -> 0xFF, others 0x00
 __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
     uint32_t m = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
@@ -944,8 +959,6 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                         // Specialised kernels: five agents per pass.  All their grid reads go out together, then all the
                         // colour-table reads, then the stores: two LDS round trips per pass instead of two per agent.
                         constexpr int kB = 5;
-                        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-                        struct __attribute__((packed, aligned(1))) P3 { u32x3 v; };
                         for (int ag0 = 0; ag0 < NA; ag0 += kB) {
                             uint32_t addr[kB][4], px[kB][4];
 #pragma unroll
@@ -973,11 +986,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                             if (lane_on) {
 #pragma unroll
                                 for (int u = 0; u < kB; ++u) {
-                                    u32x3 d;
+                                    u32x3_t d;
                                     d.x = __builtin_amdgcn_perm(px[u][1], px[u][0], 0x04020100u);   // r0 g0 b0 r1
                                     d.y = __builtin_amdgcn_perm(px[u][2], px[u][1], 0x05040201u);   // g1 b1 r2 g2
                                     d.z = __builtin_amdgcn_perm(px[u][3], px[u][2], 0x06050402u);   // b2 r3 g3 b3
-                                    reinterpret_cast<P3 *>(out_env + (size_t)(ag0 + u) * VV * 3 + off3)->v = d;
+                                    store12_wt(out_env + (size_t)(ag0 + u) * VV * 3, off3, d);
                                 }
                             }
                         }
@@ -1013,12 +1026,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                             }
                             if (VV >= 4) {
                                 if (lane_on) {
-                                    typedef float f32x4 __attribute__((ext_vector_type(4)));
-                                    struct __attribute__((packed, aligned(4))) F4 { f32x4 v; };
+                                    float *basef = reinterpret_cast<float *>(p.obs) + ((slot_en + (size_t)e * N + ag) * VV) * 3;   // wave-uniform
 #pragma unroll
                                     for (int k4 = 0; k4 < 3; ++k4) {
-                                        f32x4 v4 = {f[4 * k4], f[4 * k4 + 1], f[4 * k4 + 2], f[4 * k4 + 3]};
-                                        reinterpret_cast<F4 *>(dstf + 4 * k4)->v = v4;
+                                        f32x4_t v4 = {f[4 * k4], f[4 * k4 + 1], f[4 * k4 + 2], f[4 * k4 + 3]};
+                                        store16_wt(basef, (uint32_t)pp0 * 12u + 16u * k4, v4);
                                     }
                                 }
                             } else {
@@ -1031,15 +1043,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                         uint8_t *dst = out_env + (size_t)ag * VV * 3 + off3;
                         if (VV >= 4) {
                             if (lane_on) {
-                                typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-                                struct __attribute__((packed, aligned(1))) P3 { u32x3 v; };
-                                u32x3 d;
+                                u32x3_t d;
                                 // 4 x (r,g,b) -> 12 bytes with three byte permutes (v_perm_b32: selector bytes 0-3 pick from
                                 // the second operand, 4-7 from the first)
                                 d.x = __builtin_amdgcn_perm(px[1], px[0], 0x04020100u);   // r0 g0 b0 r1
                                 d.y = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);   // g1 b1 r2 g2
                                 d.z = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);   // b2 r3 g3 b3
-                                reinterpret_cast<P3 *>(dst)->v = d;
+                                store12_wt(out_env + (size_t)ag * VV * 3, off3, d);
                             }
                         } else {
 #pragma unroll
