@@ -134,11 +134,16 @@ __device__ __forceinline__ void unit_vec(int code, int &dr, int &dc) {
 // reads its data registers late, so a VALU write to one of them needs wait states after the store.
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store12_wt(uint8_t *base, uint32_t off, u32x3_t d) {
-    asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+// `wt` (wave-uniform, Params::obs_wt) picks the policy per launch: once a launch is many rounds of waves (above 32 768
+// envs) the kernel is bandwidth-bound, L2 merging of the 12-byte pieces matters more than the final flush, and ordinary
+// stores win (65 536 envs: 53.6 vs 69.4 us).
+__device__ __forceinline__ void store12_wt(uint8_t *base, uint32_t off, u32x3_t d, bool wt) {
+    if (wt) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+    else asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
 }
-__device__ __forceinline__ void store16_wt(float *base, uint32_t off, f32x4_t d) {
-    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+__device__ __forceinline__ void store16_wt(float *base, uint32_t off, f32x4_t d, bool wt) {
+    if (wt) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+    else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
 }
 
 // bytes of x that are non-zero -> 0xFF, others 0x00
@@ -990,7 +995,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                                     d.x = __builtin_amdgcn_perm(px[u][1], px[u][0], 0x04020100u);   // r0 g0 b0 r1
                                     d.y = __builtin_amdgcn_perm(px[u][2], px[u][1], 0x05040201u);   // g1 b1 r2 g2
                                     d.z = __builtin_amdgcn_perm(px[u][3], px[u][2], 0x06050402u);   // b2 r3 g3 b3
-                                    store12_wt(out_env + (size_t)(ag0 + u) * VV * 3, off3, d);
+                                    store12_wt(out_env + (size_t)(ag0 + u) * VV * 3, off3, d, p.obs_wt != 0);
                                 }
                             }
                         }
@@ -1030,7 +1035,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
 #pragma unroll
                                     for (int k4 = 0; k4 < 3; ++k4) {
                                         f32x4_t v4 = {f[4 * k4], f[4 * k4 + 1], f[4 * k4 + 2], f[4 * k4 + 3]};
-                                        store16_wt(basef, (uint32_t)pp0 * 12u + 16u * k4, v4);
+                                        store16_wt(basef, (uint32_t)pp0 * 12u + 16u * k4, v4, p.obs_wt != 0);
                                     }
                                 }
                             } else {
@@ -1049,7 +1054,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                                 d.x = __builtin_amdgcn_perm(px[1], px[0], 0x04020100u);   // r0 g0 b0 r1
                                 d.y = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);   // g1 b1 r2 g2
                                 d.z = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);   // b2 r3 g3 b3
-                                store12_wt(out_env + (size_t)ag * VV * 3, off3, d);
+                                store12_wt(out_env + (size_t)ag * VV * 3, off3, d, p.obs_wt != 0);
                             }
                         } else {
 #pragma unroll
@@ -1123,7 +1128,10 @@ static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipS
     }
 }
 
-void launch(const Params &p, int game, void *stream) {
+void launch(const Params &p_in, int game, void *stream) {
+    Params p = p_in;
+    static const int forced_wt = [] { const char *v = getenv("SSD_OBS_WT"); return v ? atoi(v) : -1; }();   // tuning override
+    p.obs_wt = forced_wt >= 0 ? forced_wt : ((p.E - p.e_begin) <= 32768 ? 1 : 0);
     const bool f32 = p.obs && p.obs_f32;            // the float32-observation variant is a separate instantiation
     const int epb = envs_per_block(p, f32);
     const dim3 grid((p.E - p.e_begin + epb - 1) / epb), block(64 * epb);
