@@ -223,7 +223,14 @@ __host__ int envs_per_block(const Params &p, bool f32) {
 // FAST additionally fixes the map to the game's shipped one (Harvest 16x38, Cleanup 25x18) and the call to its plain
 // form (index action order, beams not kept): another 3.8 %.
 template <int GAME, int MODE, bool F32, int NA, bool STD, bool FAST>
-__global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Params p) {
+// The leading arguments repeat the Params fields the first global loads need (14 dwords).  Built with
+// -mllvm -amdgpu-kernarg-preload-count=14 the command processor delivers them in SGPRs when the wave starts, so the
+// loads of the env's state go out without first waiting ~0.3 us for a scalar load of the kernel arguments.
+__global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *const a_hdr, uint32_t *const a_agents, uint8_t *const a_world,
+                                                                        const int a_E, const int a_e_begin, const int a_epb, const int a_n_apple,
+                                                                        const uint32_t *const a_apple_cells, const uint32_t *const a_lut,
+                                                                        const Params p) {
+    uint8_t *const a_obs = p.obs;
     extern __shared__ __align__(16) uint8_t smem[];
 #ifdef SSD_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();    // before the first kernel-argument fetch
@@ -248,15 +255,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
     uint8_t *s_occ = s_beam + S;
     uint8_t *s_view = roll ? s_occ + S + A0 : s_world;              // what the observations read: world <- agents <- beams
 
-    // Kernel arguments are fetched lazily by default, one scalar-cache round trip per basic block that
-    // needs one.  Pin what the prologue needs into SGPRs here so that the loads go out as one batch.
-    asm volatile("" ::"s"(p.hdr), "s"(p.agents), "s"(p.world), "s"(p.lut), "s"(p.apple_cells), "s"(p.obs),
-                 "s"(p.actions), "s"(p.order), "s"(p.n_apple), "s"(p.num_actions_random));
-    if (GAME == 1) asm volatile("" ::"s"(p.waste_cells), "s"(p.n_waste), "s"(p.thr_ca), "s"(p.thr_cw), "s"(p.n_thr));
-    else asm volatile("" ::"s"(p.thr_h32[0]), "s"(p.thr_h32[1]), "s"(p.thr_h32[2]), "s"(p.thr_h32[3]), "s"(p.thr_h_always));
-    const int e = p.e_begin + blockIdx.x * (int)(blockDim.x >> 6) + wv;
+    const int e = a_e_begin + blockIdx.x * a_epb + wv;      // (a_epb = blockDim.x / 64, without the implicit-argument load)
     constexpr int mode = MODE;                               // compile-time: step / reset / observe
-    bool active = e < p.E;                                   // wave-uniform
+    bool active = e < a_E;                                   // wave-uniform
     if (active && mode == kModeReset && p.mask) active = p.mask[e] != 0;
     SSD_STAMP_RT(10);
     SSD_NOTE(14, t_entry);
@@ -265,26 +266,23 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
     if (active) {
         const bool is_agent = lane < N;
         // ---- prologue: every global load of the env is issued before the first use, so the HBM / L2
-        //      latency is paid once.  hdr, agents, the first 1 KiB of the grid (the whole grid of the
-        //      shipped maps), the static cell lists and the colour table.
-        const uint4 hdr = p.hdr[e];
+        //      latency is paid once.  First the loads whose addresses come from the preloaded arguments alone (hdr, agents,
+        //      the first 1 KiB of the grid = the whole grid of the shipped maps, the colour table, the apple list), then
+        //      the ones that need further kernel arguments (actions, order, waste list).
+        const uint4 hdr = a_hdr[e];
         uint32_t areg = 0;
         int act_in = -1;
         uint32_t ord_in = 0xFFu;
-        if (mode != kModeReset && is_agent) areg = p.agents[(size_t)e * N + lane];
-        if (mode == kModeStep && is_agent) {
-            if (p.num_actions_random <= 0) act_in = p.actions[(size_t)e * N + lane];
-            if (has_order) ord_in = p.order[(size_t)e * N + lane];
-        }
-        const uint8_t *gsrc = mode == kModeReset ? p.reset_world : p.world + (size_t)e * S;
+        if (mode != kModeReset && is_agent) areg = a_agents[(size_t)e * N + lane];
+        const uint8_t *gsrc = mode == kModeReset ? p.reset_world : a_world + (size_t)e * S;
         uint4 w0 = make_uint4(0, 0, 0, 0), b0 = make_uint4(0, 0, 0, 0);
         if (lane * 16 < S) {
             w0 = *reinterpret_cast<const uint4 *>(gsrc + lane * 16);
             if (mode == kModeObserve && keep_beams) b0 = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + lane * 16);
         }
         // glyph -> RGB table of the observation phase, one copy per wave
-        const uint32_t lut_a = p.obs ? p.lut[lane] : 0u, lut_b = p.obs ? p.lut[lane + 64] : 0u;
-        const bool obs_f32 = F32 && p.obs;
+        const uint32_t lut_a = a_lut[lane], lut_b = a_lut[lane + 64];
+        const bool obs_f32 = F32 && a_obs;
         float4 flut = make_float4(0.f, 0.f, 0.f, 0.f);
         if (obs_f32) flut = reinterpret_cast<const float4 *>(p.f32lut)[lane];
         // static cell lists of the map: the first 64*kListRegs entries live in registers
@@ -292,7 +290,21 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
 #pragma unroll
         for (int j = 0; j < kListRegs; ++j) {
             const int idx = lane + 64 * j;
-            alist[j] = (mode != kModeObserve && idx < p.n_apple) ? p.apple_cells[idx] : 0u;
+            alist[j] = (mode != kModeObserve && idx < a_n_apple) ? a_apple_cells[idx] : 0u;
+        }
+        // The other kernel arguments are fetched lazily by default, one scalar-cache round trip per basic block that needs
+        // one.  Pin what the rest of the prologue and the respawn need into SGPRs here -- the loads above are in flight --
+        // so that those fetches go out as one batch.
+        asm volatile("" ::"s"(p.actions), "s"(p.order), "s"(p.num_actions_random), "s"(p.obs));
+        if (GAME == 1) asm volatile("" ::"s"(p.waste_cells), "s"(p.n_waste), "s"(p.thr_ca), "s"(p.thr_cw), "s"(p.n_thr));
+        else asm volatile("" ::"s"(p.thr_h32[0]), "s"(p.thr_h32[1]), "s"(p.thr_h32[2]), "s"(p.thr_h32[3]), "s"(p.thr_h_always));
+        if (mode == kModeStep && is_agent) {
+            if (p.num_actions_random <= 0) act_in = p.actions[(size_t)e * N + lane];
+            if (has_order) ord_in = p.order[(size_t)e * N + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < kListRegs; ++j) {
+            const int idx = lane + 64 * j;
             wlist[j] = (GAME == 1 && mode != kModeObserve && idx < p.n_waste) ? p.waste_cells[idx] : 0u;
         }
         uint32_t key = rfl(hdr.x), t = rfl(hdr.y), episode = rfl(hdr.z);
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
             *reinterpret_cast<uint4 *>(s_beam + lane * 16) = b0;
             *reinterpret_cast<uint4 *>(s_occ + lane * 16) = make_uint4(0, 0, 0, 0);
         }
-        if (p.obs) {                                         // the aprons of the layer the observations read: '0' (void) cells
+        if (a_obs) {                                         // the aprons of the layer the observations read: '0' (void) cells
             const uint4 z = make_uint4(0x30303030u, 0x30303030u, 0x30303030u, 0x30303030u);
             const int n0 = A0 >> 4, n1 = A1 >> 4;
             for (int i = lane; i < n0 + n1; i += 64)
@@ -326,14 +338,14 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
         // after the last step of a rollout launch.
         uint32_t waste_last = 0;
         auto write_state = [&]() {
-            uint8_t *gw = p.world + (size_t)e * S;
+            uint8_t *gw = a_world + (size_t)e * S;
             for (int i = lane * 16; i < S; i += 64 * 16) {
                 *reinterpret_cast<uint4 *>(gw + i) = *reinterpret_cast<const uint4 *>(s_world + i);
                 if (keep_beams)
                     *reinterpret_cast<uint4 *>(p.beam + (size_t)e * S + i) = *reinterpret_cast<const uint4 *>(s_beam + i);
             }
-            if (is_agent) p.agents[(size_t)e * N + lane] = cell | (orient << 16);
-            if (lane == 0) p.hdr[e] = make_uint4(key, t, episode, waste_last);
+            if (is_agent) a_agents[(size_t)e * N + lane] = cell | (orient << 16);
+            if (lane == 0) a_hdr[e] = make_uint4(key, t, episode, waste_last);
             if (status && lane == 0) atomicOr(p.status, status);
         };
         // ---- One pass = one reset or one step of the env.  A step / reset / observe launch makes one pass.  A rollout
@@ -811,7 +823,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                         for (int j = kListRegs; j < a_iters; ++j) {
                             const int idx = lane + 64 * j;
                             const bool valid = idx < p.n_apple;
-                            const uint32_t c = valid ? p.apple_cells[idx] : safe;
+                            const uint32_t c = valid ? a_apple_cells[idx] : safe;
                             const bool cand = valid & (s_world[c & 0xFFFFu] != 'A') & (s_occ[c & 0xFFFFu] == 0);
                             spawn_bits |= (cand & wins(c)) ? bit(j) : 0ull;
                         }
@@ -838,7 +850,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                     for (int j = 0; j < kListRegs; ++j) apple(j, alist[j], lane + 64 * j < p.n_apple);
                     for (int j = kListRegs; j < a_iters; ++j) {
                         const int idx = lane + 64 * j;
-                        apple(j, idx < p.n_apple ? p.apple_cells[idx] : 0u, idx < p.n_apple);
+                        apple(j, idx < p.n_apple ? a_apple_cells[idx] : 0u, idx < p.n_apple);
                     }
                     if (thr_w) {
                         // :144-153 shuffled scan, first non-'H' point whose coin succeeds (at most one per step):
@@ -871,7 +883,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                 for (int j = 0; j < kListRegs; ++j)
                     if ((spawn_bits >> j) & 1) s_world[alist[j] & 0xFFFFu] = 'A';
                 for (int j = kListRegs; j < a_iters; ++j)
-                    if ((spawn_bits >> j) & 1) s_world[p.apple_cells[lane + 64 * j] & 0xFFFFu] = 'A';
+                    if ((spawn_bits >> j) & 1) s_world[a_apple_cells[lane + 64 * j] & 0xFFFFu] = 'A';
                 if (waste_cell != 0xFFFFFFFFu) s_world[waste_cell] = 'H';               // may land under an agent
                 wave_sync();
 
@@ -922,11 +934,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
             //      Thanks to the padded grid layout a view cell is ONE multiply-add away from its LDS address.
             //      An agent's block starts at a multiple of V*V*3 = 675 bytes, i.e. at any byte alignment:
             //      the 12-byte stores rely on gfx9's unaligned global access. ----
-            if (p.obs && (!roll || is_step)) {
+            if (a_obs && (!roll || is_step)) {
                 typedef __attribute__((address_space(3))) const uint8_t lds_u8;
                 const int V = STD ? 15 : p.V, v = STD ? 7 : p.view_len, VV = V * V;
                 // (diagnostic builds, skip bit 4: all envs write the first 64 envs' blocks -- same instructions, no HBM write stream)
-                uint8_t *out_env = p.obs + (slot_en + (size_t)(SSD_SKIP(4) ? (e & 63) : e) * N) * VV * 3;
+                uint8_t *out_env = a_obs + (slot_en + (size_t)(SSD_SKIP(4) ? (e & 63) : e) * N) * VV * 3;
                 // Per-agent constants, computed once with lane = agent and read back as scalars in the loop.
                 // Window cell (a, b) of an agent on grid cell `cell` is grid cell cell + (a - v) * WP + (b - v).
                 // The view is rot90^k of the window (rotate_view, map_env.py:669-689; UP 0, LEFT 1, DOWN 2,
@@ -1021,7 +1033,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                         if (obs_f32) {
                             // float32 mode: 3 floats per cell through the exact byte -> float table, 48 contiguous
                             // bytes per lane (three 16-byte stores; an agent block starts at a multiple of 2700 B)
-                            float *dstf = reinterpret_cast<float *>(p.obs) + ((slot_en + (size_t)e * N) * VV + cell0) * 3;
+                            float *dstf = reinterpret_cast<float *>(a_obs) + ((slot_en + (size_t)e * N) * VV + cell0) * 3;
                             float f[12];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
@@ -1031,7 +1043,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(const Pa
                             }
                             if (VV >= 4) {
                                 if (lane_on) {
-                                    float *basef = reinterpret_cast<float *>(p.obs) + ((slot_en + (size_t)e * N + ag) * VV) * 3;   // wave-uniform
+                                    float *basef = reinterpret_cast<float *>(a_obs) + ((slot_en + (size_t)e * N + ag) * VV) * 3;   // wave-uniform
 #pragma unroll
                                     for (int k4 = 0; k4 < 3; ++k4) {
                                         f32x4_t v4 = {f[4 * k4], f[4 * k4 + 1], f[4 * k4 + 2], f[4 * k4 + 3]};
@@ -1098,9 +1110,9 @@ __global__ void ssd_render_full_kernel(const Params p, int e, uint8_t *rgb) {
 template <int GAME, bool F32, int NA, bool STD, bool FAST>
 static void launch_step(const Params &p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
     if (p.mode == kModeRollout) {
-        if constexpr (!F32) hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeRollout, false, NA, STD, FAST>), grid, block, lds, s, p);
+        if constexpr (!F32) hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeRollout, false, NA, STD, FAST>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
     } else {
-        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStep, F32, NA, STD, FAST>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStep, F32, NA, STD, FAST>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
     }
 }
 
@@ -1122,9 +1134,9 @@ static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipS
         } else if (std_view) launch_step<GAME, F32, 0, true, false>(p, grid, block, lds, s);
         else launch_step<GAME, F32, 0, false, false>(p, grid, block, lds, s);
     } else if (p.mode == kModeReset) {
-        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeReset, F32, 0, false, false>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeReset, F32, 0, false, false>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
     } else {
-        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeObserve, F32, 0, false, false>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeObserve, F32, 0, false, false>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
     }
 }
 
