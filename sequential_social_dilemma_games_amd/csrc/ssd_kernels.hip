@@ -134,8 +134,8 @@ __device__ __forceinline__ void unit_vec(int code, int &dr, int &dc) {
 // reads its data registers late, so a VALU write to one of them needs wait states after the store.
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-// `wt` (wave-uniform, Params::obs_wt) picks the policy per launch: once a launch is many rounds of waves (above 32 768
-// envs) the kernel is bandwidth-bound, L2 merging of the 12-byte pieces matters more than the final flush, and ordinary
+// `wt` (wave-uniform, Params::obs_wt) picks the policy per launch: once a launch is many rounds of waves (above 16 384
+// envs per launch, two launches in flight) the kernel is bandwidth-bound, L2 merging of the 12-byte pieces matters more than the final flush, and ordinary
 // stores win (65 536 envs: 53.6 vs 69.4 us).
 __device__ __forceinline__ void store12_wt(uint8_t *base, uint32_t off, u32x3_t d, bool wt) {
     if (wt) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
@@ -1143,7 +1143,7 @@ static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipS
 void launch(const Params &p_in, int game, void *stream) {
     Params p = p_in;
     static const int forced_wt = [] { const char *v = getenv("SSD_OBS_WT"); return v ? atoi(v) : -1; }();   // tuning override
-    p.obs_wt = forced_wt >= 0 ? forced_wt : ((p.E - p.e_begin) <= 32768 ? 1 : 0);
+    p.obs_wt = forced_wt >= 0 ? forced_wt : ((p.E - p.e_begin) <= 16384 ? 1 : 0);   // per launch; rollouts run two launches at a time
     const bool f32 = p.obs && p.obs_f32;            // the float32-observation variant is a separate instantiation
     const int epb = envs_per_block(p, f32);
     const dim3 grid((p.E - p.e_begin + epb - 1) / epb), block(64 * epb);
