@@ -628,8 +628,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     // Cleanup: a CLEAN beam turns the 'H' that stops it into 'R' (cleanup.py:94-111), which a later CLEAN beam
                     // would pass through, and 'F' / 'C' marks overwrite each other in action order -- but only where the beams
                     // of two shooters cover the same cell.  So: trace them all at once against the unchanged map, let every
-                    // covered cell be claimed by its shooter's slot, and if any lane finds its cell claimed by another slot
-                    // (beams of two shooters overlap) undo the claims and trace the shooters one after the other instead.
+                    // covered cell be claimed by its shooter's slot, and if any lane finds its cell claimed by another slot in
+                    // a way that matters (below) undo the claims and trace the shooters one after the other instead.
                     const uint64_t all_shooters = shooters;
                     beams_in_regs = __builtin_popcountll(all_shooters) <= G;            // one pass covers them all
                     const int g = STD ? lane / 15 : lane / R, r = lane - g * R;
@@ -670,10 +670,15 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                         const int len = fs < ff ? fs + 1 : ff;                          // beam covers the stopping cell
                         const bool covered = inray & (kk < len);
                         if (GAME == 1 && (all_shooters & (all_shooters - 1))) {         // two or more shooters
-                            if (covered) s_beam[cidx] = (uint8_t)(g + 1);               // claim (the beam layer is empty at this point)
+                            // claim = slot, and the beam's kind.  Sharing a cell only matters if the two beams differ in kind
+                            // (which mark survives depends on the order) or both are CLEAN beams stopped by that very 'H'
+                            // (the second one would find it cleaned and go on); 'F' over 'F' and 'C' over 'C' are the same
+                            // either way, and FIRE beams do not see each other.
+                            const uint8_t mine = (uint8_t)((g + 1) | (clean ? 0x10 : 0));
+                            if (covered) s_beam[cidx] = mine;                           // (the beam layer is empty at this point)
                             wave_sync();
                             const uint8_t claimed = s_beam[cidx];
-                            if (ballot(covered & (claimed != (uint8_t)(g + 1)))) {      // two shooters' beams share a cell
+                            if (ballot(covered & (claimed != mine) & ((((claimed ^ mine) & 0x10) != 0) | (clean & (wch == 'H'))))) {
                                 if (covered) s_beam[cidx] = 0;
                                 wave_sync();
                                 shooters = all_shooters;                                // -> one after the other, below
