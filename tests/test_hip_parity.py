@@ -456,3 +456,33 @@ def test_fused_rollout_specialisations(cfg):
     eng = VecEngine(game, amap, num_envs=E, num_agents=N, seed=5)
     ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), seed=5)
     _fused_vs_oracle(eng, ora, E, N, 15, steps=31, every=10, ring=3)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_rollout_random_edge_cases(fused):
+    """n_steps = 0 is a no-op; reset_every = 1 resets before every step; more chains than envs; a ring longer than the
+    rollout; and bad arguments are rejected."""
+    import torch
+    from sequential_social_dilemma_games_amd import _capi
+    E, N = 5, 3
+    eng = VecEngine(K.GAME_CLEANUP, None, num_envs=E, num_agents=N, seed=21)
+    ora = pyoracle.Oracle(K.GAME_CLEANUP, K.CLEANUP_MAP, E, N, G.default_lut(), seed=21)
+    obs = torch.zeros((6, E, N, 15, 15, 3), dtype=torch.uint8, device="cuda")
+    rew = torch.zeros((6, E, N), dtype=torch.int32, device="cuda")
+    eng.set_rollout_chains(8)                                   # clipped to the 5 envs
+    eng.rollout_random(0, obs, rew, None, reset_every=1, fused=fused)
+    assert (eng.get_state()["episode"] == 0xFFFFFFFF).all()     # nothing happened: never reset
+    eng.rollout_random(4, obs, rew, None, reset_every=1, step0=3, fused=fused)
+    for k in range(3, 7):
+        ora.reset()
+        _, o_obs, o_rew, _ = ora.step_random()
+        np.testing.assert_array_equal(obs[k % 6].cpu().numpy(), o_obs, err_msg="obs of step %d" % k)
+        np.testing.assert_array_equal(rew[k % 6].cpu().numpy(), o_rew, err_msg="rew of step %d" % k)
+    a, b = eng.get_state(), ora.get_state()
+    for key in ("world", "pos", "orient", "episode", "t"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    with pytest.raises(_capi.SsdError):
+        eng.rollout_random(-1, obs, rew, None, fused=fused)
+    with pytest.raises(_capi.SsdError):
+        eng.set_rollout_chains(9)
+    assert eng.status() == 0
