@@ -29,6 +29,11 @@ struct ssd_env {
     // staging for SSD_HOST_PTRS
     int32_t *st_actions = nullptr, *st_rew = nullptr, *st_actions_out = nullptr;
     float *st_obs_f32 = nullptr;
+    // small handles (the dict API's single env): host-pinned, device-mapped staging -- the kernel reads / writes it
+    // directly, so a host-pointer call is one launch + one synchronise instead of five copies
+    bool st_mapped = false;
+    uint8_t *st_host = nullptr;      // host view of the mapped block; the st_* pointers above are its device view
+    std::vector<void *> host_allocs;
     uint8_t *st_order = nullptr, *st_obs = nullptr, *st_done = nullptr, *st_mask = nullptr, *st_rgb = nullptr;
     // ssd_rollout_random: extra chains (streams + fork / join events), created on first use
     std::vector<hipStream_t> chain_streams;
@@ -115,6 +120,26 @@ int ensure_staging(ssd_env *env) {
     if (env->st_obs) return SSD_OK;
     const size_t en = (size_t)env->E * env->N;
     int rc;
+    const size_t a16 = 15;
+    const size_t o_act = 0, o_aout = (o_act + en * 4 + a16) & ~a16, o_rew = (o_aout + en * 4 + a16) & ~a16,
+                 o_ord = (o_rew + en * 4 + a16) & ~a16, o_done = (o_ord + en + a16) & ~a16, o_mask = (o_done + en + a16) & ~a16,
+                 o_obs = (o_mask + (size_t)env->E + a16) & ~a16, o_f32 = (o_obs + obs_bytes(env) + a16) & ~a16,
+                 total = o_f32 + obs_bytes(env, true);
+    if (total <= (1u << 20)) {
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, total, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+            std::memset(h, 0, total);
+            env->host_allocs.push_back(h);
+            env->st_mapped = true; env->st_host = static_cast<uint8_t *>(h);
+            uint8_t *b = static_cast<uint8_t *>(d);
+            env->st_actions = reinterpret_cast<int32_t *>(b + o_act); env->st_actions_out = reinterpret_cast<int32_t *>(b + o_aout);
+            env->st_rew = reinterpret_cast<int32_t *>(b + o_rew); env->st_order = b + o_ord; env->st_done = b + o_done;
+            env->st_mask = b + o_mask; env->st_obs = b + o_obs; env->st_obs_f32 = reinterpret_cast<float *>(b + o_f32);
+            return SSD_OK;
+        }
+        if (h) (void)hipHostFree(h);
+        (void)hipGetLastError();                 // fall back to device staging
+    }
     if ((rc = dev_alloc(env, &env->st_actions, en))) return rc;
     if ((rc = dev_alloc(env, &env->st_actions_out, en))) return rc;
     if ((rc = dev_alloc(env, &env->st_rew, en))) return rc;
@@ -150,6 +175,28 @@ int run(ssd_env *env, int mode, const int32_t *actions, const uint8_t *order, co
     }
     int rc = ensure_staging(env);
     if (rc) return rc;
+    if (env->st_mapped) {
+        // the staging block is host memory the GPU addresses directly: plain memcpy in, one launch, one wait, memcpy out
+        auto hostp = [&](const void *dev) { return env->st_host + (static_cast<const uint8_t *>(dev) - reinterpret_cast<const uint8_t *>(env->st_actions)); };
+        if (actions) { std::memcpy(hostp(env->st_actions), actions, en * sizeof(int32_t)); p.actions = env->st_actions; }
+        if (order) { std::memcpy(hostp(env->st_order), order, en); p.order = env->st_order; }
+        if (mask) { std::memcpy(hostp(env->st_mask), mask, (size_t)env->E); p.mask = env->st_mask; }
+        if (actions_out) p.actions_out = env->st_actions_out;
+        if (obs) {
+            p.obs = f32 ? reinterpret_cast<uint8_t *>(env->st_obs_f32) : env->st_obs;
+            if (mask) std::memcpy(hostp(p.obs), obs, obs_bytes(env, f32));      // rows of envs that are not reset come back unchanged
+        }
+        if (rew) p.rew = env->st_rew;
+        if (done) p.done = env->st_done;
+        ssd::launch(p, env->game, stream);
+        SSD_HIP(env, hipGetLastError());
+        SSD_HIP(env, hipStreamSynchronize(s));
+        if (actions_out) std::memcpy(actions_out, hostp(env->st_actions_out), en * sizeof(int32_t));
+        if (obs) std::memcpy(obs, hostp(p.obs), obs_bytes(env, f32));
+        if (rew) std::memcpy(rew, hostp(env->st_rew), en * sizeof(int32_t));
+        if (done) std::memcpy(done, hostp(env->st_done), en);
+        return SSD_OK;
+    }
     if (actions) { SSD_HIP(env, hipMemcpyAsync(env->st_actions, actions, en * sizeof(int32_t), hipMemcpyHostToDevice, s)); p.actions = env->st_actions; }
     if (order) { SSD_HIP(env, hipMemcpyAsync(env->st_order, order, en, hipMemcpyHostToDevice, s)); p.order = env->st_order; }
     if (mask) { SSD_HIP(env, hipMemcpyAsync(env->st_mask, mask, (size_t)env->E, hipMemcpyHostToDevice, s)); p.mask = env->st_mask; }
@@ -331,6 +378,7 @@ int ssd_destroy(ssd_env *env) {
     (void)hipSetDevice(env->device);
     (void)hipDeviceSynchronize();
     for (void *ptr : env->allocs) (void)hipFree(ptr);
+    for (void *ptr : env->host_allocs) (void)hipHostFree(ptr);
     for (hipStream_t cs : env->chain_streams) (void)hipStreamDestroy(cs);
     for (hipEvent_t ce : env->chain_events) (void)hipEventDestroy(ce);
     if (env->fork_event) (void)hipEventDestroy(env->fork_event);
