@@ -244,6 +244,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     const int S = FAST ? (GAME == 0 ? 720 : 640) : p.S;
     const int A0 = FAST ? (GAME == 0 ? 336 : 192) : p.A0, A1 = FAST ? (GAME == 0 ? 320 : 176) : p.A1;
     const int N = NA > 0 ? NA : p.N;
+    // sizes of the map's cell lists (FAST: the shipped maps' -- launch_game() checks them): lets the compiler drop the
+    // unused third list register of Cleanup's 103 apple / 119 waste points
+    const int n_apple = FAST ? (GAME == 0 ? 155 : 103) : a_n_apple, n_waste = FAST ? 119 : p.n_waste;
     const bool has_order = !FAST && p.order != nullptr, keep_beams = !FAST && p.keep_beams != 0;
     constexpr bool roll = MODE == kModeRollout;                     // many steps per launch, env resident in LDS
     uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + (size_t)wv * (512 + 256 + (F32 ? 1024 : 0) + (size_t)A0 + (size_t)A1 +
@@ -290,13 +293,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
 #pragma unroll
         for (int j = 0; j < kListRegs; ++j) {
             const int idx = lane + 64 * j;
-            alist[j] = (mode != kModeObserve && idx < a_n_apple) ? a_apple_cells[idx] : 0u;
+            alist[j] = (mode != kModeObserve && idx < n_apple) ? a_apple_cells[idx] : 0u;
         }
         // The other kernel arguments are fetched lazily by default, one scalar-cache round trip per basic block that needs
         // one.  Pin what the rest of the prologue and the respawn need into SGPRs here -- the loads above are in flight --
         // so that those fetches go out as one batch.
         asm volatile("" ::"s"(p.actions), "s"(p.order), "s"(p.num_actions_random), "s"(p.obs));
-        if (GAME == 1) asm volatile("" ::"s"(p.waste_cells), "s"(p.n_waste), "s"(p.thr_ca), "s"(p.thr_cw), "s"(p.n_thr));
+        if (GAME == 1) asm volatile("" ::"s"(p.waste_cells), "s"(n_waste), "s"(p.thr_ca), "s"(p.thr_cw), "s"(p.n_thr));
         else asm volatile("" ::"s"(p.thr_h32[0]), "s"(p.thr_h32[1]), "s"(p.thr_h32[2]), "s"(p.thr_h32[3]), "s"(p.thr_h_always));
         if (mode == kModeStep && is_agent) {
             if (p.num_actions_random <= 0) act_in = p.actions[(size_t)e * N + lane];
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
 #pragma unroll
         for (int j = 0; j < kListRegs; ++j) {
             const int idx = lane + 64 * j;
-            wlist[j] = (GAME == 1 && mode != kModeObserve && idx < p.n_waste) ? p.waste_cells[idx] : 0u;
+            wlist[j] = (GAME == 1 && mode != kModeObserve && idx < n_waste) ? p.waste_cells[idx] : 0u;
         }
         uint32_t key = rfl(hdr.x), t = rfl(hdr.y), episode = rfl(hdr.z);
         s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b;
@@ -760,7 +763,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 // cell), so they go out as one independent batch.
                 uint64_t spawn_bits = 0;                                                // bit j: list entry lane + 64*j gets an apple
                 const uint32_t pk_apple = phase_key(key, t, kApple);
-                const int a_iters = (p.n_apple + 63) >> 6;
+                const int a_iters = (n_apple + 63) >> 6;
                 const uint32_t safe = (uint32_t)(WP + 1);                               // cell (1,1)
                 uint32_t waste_cell = 0xFFFFFFFFu;
                 uint32_t waste_count = 0;                                               // #'H' the probabilities were computed from
@@ -827,7 +830,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                         }
                         for (int j = kListRegs; j < a_iters; ++j) {
                             const int idx = lane + 64 * j;
-                            const bool valid = idx < p.n_apple;
+                            const bool valid = idx < n_apple;
                             const uint32_t c = valid ? a_apple_cells[idx] : safe;
                             const bool cand = valid & (s_world[c & 0xFFFFu] != 'A') & (s_occ[c & 0xFFFFu] == 0);
                             spawn_bits |= (cand & wins(c)) ? bit(j) : 0ull;
@@ -852,10 +855,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                         spawn_bits |= hit ? bit(j) : 0ull;
                     };
 #pragma unroll
-                    for (int j = 0; j < kListRegs; ++j) apple(j, alist[j], lane + 64 * j < p.n_apple);
+                    for (int j = 0; j < kListRegs; ++j)
+                        if (64 * j < n_apple) apple(j, alist[j], lane + 64 * j < n_apple);   // (wave-uniform: skips unused list registers)
                     for (int j = kListRegs; j < a_iters; ++j) {
                         const int idx = lane + 64 * j;
-                        apple(j, idx < p.n_apple ? a_apple_cells[idx] : 0u, idx < p.n_apple);
+                        apple(j, idx < n_apple ? a_apple_cells[idx] : 0u, idx < n_apple);
                     }
                     if (thr_w) {
                         // :144-153 shuffled scan, first non-'H' point whose coin succeeds (at most one per step):
@@ -871,12 +875,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                             const bool better = cand & (!has | (kh < bh) | ((kh == bh) & (c < bl)));
                             bh = better ? kh : bh; bl = better ? c : bl; has = has | cand;
                         };
-                        const int w_iters = (p.n_waste + 63) >> 6;
+                        const int w_iters = (n_waste + 63) >> 6;
 #pragma unroll
-                        for (int j = 0; j < kListRegs; ++j) waste(wlist[j], lane + 64 * j < p.n_waste);
+                        for (int j = 0; j < kListRegs; ++j)
+                            if (64 * j < n_waste) waste(wlist[j], lane + 64 * j < n_waste);
                         for (int j = kListRegs; j < w_iters; ++j) {
                             const int idx = lane + 64 * j;
-                            waste(idx < p.n_waste ? p.waste_cells[idx] : 0u, idx < p.n_waste);
+                            waste(idx < n_waste ? p.waste_cells[idx] : 0u, idx < n_waste);
                         }
                         uint32_t oh, ol;
                         if (wave_argmin_pair(has, bh, bl, oh, ol)) waste_cell = ol;
@@ -1128,8 +1133,9 @@ static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipS
         // among those the FAST ones for the game's shipped map called in the plain way
         const bool std_view = p.view_len == 7 && p.beam_len == 5;
         const bool fast = std_view && !p.order && !p.keep_beams &&
-                          (GAME == 0 ? (p.H == 16 && p.W == 38 && p.WP == 45 && p.S == 720 && p.A0 == 336 && p.A1 == 320)
-                                     : (p.H == 25 && p.W == 18 && p.WP == 25 && p.S == 640 && p.A0 == 192 && p.A1 == 176));
+                          (GAME == 0 ? (p.H == 16 && p.W == 38 && p.WP == 45 && p.S == 720 && p.A0 == 336 && p.A1 == 320 && p.n_apple == 155)
+                                     : (p.H == 25 && p.W == 18 && p.WP == 25 && p.S == 640 && p.A0 == 192 && p.A1 == 176 &&
+                                        p.n_apple == 103 && p.n_waste == 119));
         if (std_view && p.N == 5) {
             if (fast) launch_step<GAME, F32, 5, true, true>(p, grid, block, lds, s);
             else launch_step<GAME, F32, 5, true, false>(p, grid, block, lds, s);
