@@ -414,18 +414,18 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             if (is_step) {
                 t += 1;
                 // ---- actions (map_env.py:171-173) ----
+                constexpr int kNumActions = GAME == 0 ? 8 : 9;   // harvest.py:44, cleanup.py:70
                 if (roll || p.num_actions_random > 0) {          // rollout.py:64-65 uniform random actions (a rollout launch: always)
                     const uint32_t pk = phase_key(key, t, kAction);
                     if (is_agent) {
                         act = (int)randint(draw(pk, (uint32_t)lane), (uint32_t)p.num_actions_random);
                         if (!roll && p.actions_out) p.actions_out[(size_t)e * N + lane] = act;
                     }
-                } else {
+                } else {                                         // (drawn actions are valid by construction: ssd_step_random checks n)
                     act = act_in;
+                    const bool bad = is_agent && (act < -1 || act >= kNumActions);
+                    if (ballot(bad)) { status |= kStBadAction; if (bad) act = -1; }
                 }
-                constexpr int kNumActions = GAME == 0 ? 8 : 9;   // harvest.py:44, cleanup.py:70
-                const bool bad = is_agent && (act < -1 || act >= kNumActions);
-                if (ballot(bad)) { status |= kStBadAction; if (bad) act = -1; }
                 if (has_order) {
                     ordv = ord_in;
                     if (ordv != 0xFFu && ordv >= (uint32_t)N) { ordv = 0xFFu; status |= kStBadAction; }
