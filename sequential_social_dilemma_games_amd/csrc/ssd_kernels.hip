@@ -855,12 +855,14 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                         const bool hit = valid & (w != 'A') & (o == 0) & ((uint64_t)draw(pk_apple, c >> 16) < thr_a);
                         spawn_bits |= hit ? bit(j) : 0ull;
                     };
+                    if (thr_a) {                                                        // (density >= thresholdDepletion: nothing grows, :161-163)
 #pragma unroll
-                    for (int j = 0; j < kListRegs; ++j)
-                        if (64 * j < n_apple) apple(j, alist[j], lane + 64 * j < n_apple);   // (wave-uniform: skips unused list registers)
-                    for (int j = kListRegs; j < a_iters; ++j) {
-                        const int idx = lane + 64 * j;
-                        apple(j, idx < n_apple ? a_apple_cells[idx] : 0u, idx < n_apple);
+                        for (int j = 0; j < kListRegs; ++j)
+                            if (64 * j < n_apple) apple(j, alist[j], lane + 64 * j < n_apple);   // (wave-uniform: skips unused list registers)
+                        for (int j = kListRegs; j < a_iters; ++j) {
+                            const int idx = lane + 64 * j;
+                            apple(j, idx < n_apple ? a_apple_cells[idx] : 0u, idx < n_apple);
+                        }
                     }
                     if (thr_w) {
                         // :144-153 shuffled scan, first non-'H' point whose coin succeeds (at most one per step):
