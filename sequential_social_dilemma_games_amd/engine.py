@@ -55,6 +55,10 @@ class VecEngine(object):
         _capi.check(L.ssd_create(C.byref(c), C.byref(self._h)))
         self._L = L
         self._out_cache = (None, None)               # (outputs tuple, its pointers) of the last step_random call
+        # Steps since the last reset of ALL envs, or None once envs may be at different points of their episodes (a masked
+        # reset, set_state(t=...)): lets SSDVectorEnv know, without asking the device, on which step everybody reaches the
+        # horizon.
+        self.steps_since_full_reset = None
         self._torch_dev = None
         if L.ssd_potential_waste_area(self._h) != self.potential_waste_area:
             raise _capi.SsdError("potential_waste_area mismatch between host and library")
@@ -121,6 +125,7 @@ class VecEngine(object):
         if mask is not None:
             self._check_tensor(mask, (self.E,), torch.uint8, "mask")
         _capi.check(self._L.ssd_reset(self._h, self._dp(mask), self._dp(obs), self._obs_flags(obs), self._stream()), self._h)
+        self.steps_since_full_reset = 0 if mask is None else None
         return obs
 
     def step(self, actions, order=None, out=None):
@@ -133,6 +138,7 @@ class VecEngine(object):
         obs, rew, done = out if out is not None else self.alloc_outputs()
         _capi.check(self._L.ssd_step(self._h, self._dp(actions), self._dp(order), self._dp(obs), self._dp(rew),
                                      self._dp(done), self._obs_flags(obs), self._stream()), self._h)
+        self._count_steps(1)
         return obs, rew, done
 
     def step_random(self, out=None, actions_out=None, num_actions=None):
@@ -148,7 +154,12 @@ class VecEngine(object):
         rc = self._L.ssd_step_random(self._h, na, self._dp(actions_out), po, pr, pd, fl, self._stream())
         if rc:
             _capi.check(rc, self._h)
+        self._count_steps(1)
         return obs, rew, done
+
+    def _count_steps(self, n):
+        if self.steps_since_full_reset is not None:
+            self.steps_since_full_reset += n
 
     def set_rollout_chains(self, chains):
         """How many independent env ranges rollout_random() enqueues on streams of its own (0 = automatic)."""
@@ -175,6 +186,15 @@ class VecEngine(object):
                                                self._dp(done), ring, (_capi.SSD_OBS_F32 if obs.dtype == torch.float32 else 0) |
                                                (_capi.SSD_ROLLOUT_FUSED if fused else 0),
                                                self._stream()), self._h)
+        n_steps, reset_every, step0 = int(n_steps), int(reset_every), int(step0)
+        last = None                                  # index of the last step of this call that a full reset preceded
+        if reset_every > 0 and n_steps > 0:
+            k = (n_steps - 1) - ((step0 + n_steps - 1) % reset_every)
+            last = k if k >= 0 else None
+        if last is not None:
+            self.steps_since_full_reset = n_steps - last
+        else:
+            self._count_steps(n_steps)
 
     def observe(self, rotate=True, obs=None):
         torch, dev = self._torch()
@@ -193,6 +213,7 @@ class VecEngine(object):
         obs = np.zeros((self.E, self.N, self.V, self.V, 3), np.uint8)
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.E)
         _capi.check(self._L.ssd_reset(self._h, _ptr(m), _ptr(obs), _capi.SSD_HOST_PTRS, None), self._h)
+        self.steps_since_full_reset = 0 if mask is None else None
         return obs
 
     def step_host(self, actions, order=None):
@@ -202,6 +223,7 @@ class VecEngine(object):
         obs, rew, done = self._host_out()
         _capi.check(self._L.ssd_step(self._h, _ptr(actions), _ptr(order), _ptr(obs), _ptr(rew), _ptr(done),
                                      _capi.SSD_HOST_PTRS, None), self._h)
+        self._count_steps(1)
         return obs, rew, done
 
     def step_random_host(self):
@@ -209,6 +231,7 @@ class VecEngine(object):
         obs, rew, done = self._host_out()
         _capi.check(self._L.ssd_step_random(self._h, self.num_actions, _ptr(act), _ptr(obs), _ptr(rew), _ptr(done),
                                             _capi.SSD_HOST_PTRS, None), self._h)
+        self._count_steps(1)
         return act, obs, rew, done
 
     def observe_host(self, rotate=True):
@@ -242,6 +265,8 @@ class VecEngine(object):
         episode, t = prep(episode, np.uint32, (E,), "episode"), prep(t, np.uint32, (E,), "t")
         _capi.check(self._L.ssd_set_state(self._h, _ptr(world), _ptr(beam), _ptr(pos), _ptr(orient), _ptr(episode),
                                           _ptr(t)), self._h)
+        if t is not None:
+            self.steps_since_full_reset = None
 
     def set_horizon(self, horizon):
         """done = (t >= horizon) from now on (RLlib's `horizon`, train_baseline.py:131); 0 = never (reference envs)."""

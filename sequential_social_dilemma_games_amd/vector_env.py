@@ -39,20 +39,30 @@ class SSDVectorEnv(object):
         self.engine.reset(obs=self._out[0])
         return self._out[0]
 
+    def _auto_reset(self, obs, done):
+        if self.horizon <= 0 or not self.num_agents:
+            return
+        since = self.engine.steps_since_full_reset
+        if since is not None:
+            # every env was last reset by the same call (the engine keeps track): they all reach the horizon on the same
+            # step, the host knows which one, and until then there is nothing to launch
+            if since >= self.horizon:
+                self.engine.reset(obs=obs)           # everybody just finished: a full reset, no mask needed
+            return
+        # envs at different points of their episodes: every agent of an env finishes together; a masked reset only
+        # touches envs whose flag is set, so no host synchronisation is needed to decide whether anything finished
+        self.engine.reset(mask=done[:, 0].contiguous(), obs=obs)
+
     def step(self, actions):
         """actions: int32 [E,N] on the device.  Returns (obs u8, rew i32, done u8) device tensors; envs whose
         episode just ended have been reset and their obs rows replaced by the new episode's first observation."""
         obs, rew, done = self.engine.step(actions, out=self._out)
-        if self.horizon > 0 and self.num_agents:
-            # every agent of an env finishes together; a masked reset only touches envs whose flag is set,
-            # so no host synchronisation is needed to decide whether anything finished
-            self.engine.reset(mask=done[:, 0].contiguous(), obs=obs)
+        self._auto_reset(obs, done)
         return obs, rew, done
 
     def step_random(self):
         obs, rew, done = self.engine.step_random(out=self._out)
-        if self.horizon > 0 and self.num_agents:
-            self.engine.reset(mask=done[:, 0].contiguous(), obs=obs)
+        self._auto_reset(obs, done)
         return obs, rew, done
 
     @staticmethod

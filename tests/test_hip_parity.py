@@ -486,3 +486,36 @@ def test_rollout_random_edge_cases(fused):
     with pytest.raises(_capi.SsdError):
         eng.set_rollout_chains(9)
     assert eng.status() == 0
+
+
+def test_vector_env_in_sync_resets_only_on_the_horizon_step():
+    """While all envs were reset together the adapter knows on which step they finish: no reset launch until then, a full
+    reset exactly then; results as with a masked reset after every step.  A rollout call keeps the count."""
+    import torch
+    from sequential_social_dilemma_games_amd.vector_env import SSDVectorEnv
+    E, N, Hz = 33, 5, 5
+    venv = SSDVectorEnv(K.GAME_HARVEST, E, N, horizon=Hz, seed=8)
+    ora = pyoracle.Oracle(K.GAME_HARVEST, K.HARVEST_MAP, E, N, G.default_lut(), seed=8)
+    np.testing.assert_array_equal(venv.reset().cpu().numpy(), ora.reset())
+    calls = []
+    real_reset = venv.engine.reset
+    venv.engine.reset = lambda *a, **kw: (calls.append(kw.get("mask") is not None), real_reset(*a, **kw))[1]
+    rng = np.random.RandomState(5)
+    for s in range(13):
+        act = rng.randint(0, 8, size=(E, N)).astype(np.int32)
+        obs, rew, done = venv.step(torch.from_numpy(act).cuda())
+        o_obs, o_rew, _ = ora.step(act)
+        finished = (s + 1) % Hz == 0
+        if finished:
+            o_obs = ora.reset()
+        assert bool(done.all().item()) == finished and bool(done.any().item()) == finished
+        np.testing.assert_array_equal(rew.cpu().numpy(), o_rew)
+        np.testing.assert_array_equal(obs.cpu().numpy(), o_obs, err_msg="step %d" % s)
+    assert calls == [False, False]                             # two full resets (steps 5 and 10), never a masked one
+    assert venv.engine.steps_since_full_reset == 3
+    ring = tuple(t.unsqueeze(0) for t in venv._out)
+    venv.engine.rollout_random(4, *ring, reset_every=3, step0=1)     # resets before its steps 2 (and no other): 2 steps since
+    assert venv.engine.steps_since_full_reset == 2
+    venv.engine.reset = real_reset
+    venv.try_reset(0)
+    assert venv.engine.steps_since_full_reset is None
