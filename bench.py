@@ -183,9 +183,9 @@ def main():
     ev1.record()
     enq = time.perf_counter() - t0                 # host time to enqueue the K steps (must stay below the device time)
     torch.cuda.synchronize()
-    parallel.barrier(dist, local_rank)
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+    wall = time.perf_counter() - t0                # this rank's K steps, start barrier to its own completion; MAX over ranks below
+    parallel.barrier(dist, local_rank)             # (the closing barrier: everybody is done before anybody reports; its own
+    torch.cuda.synchronize()                       #  latency, ~1 ms of RCCL, is not part of any rank's K steps)
     dev_ms = ev0.elapsed_time(ev1)
     if eng.status() != 0:
         raise SystemExit("device status word is non-zero")
