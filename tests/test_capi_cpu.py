@@ -50,3 +50,22 @@ def test_engine_fails_loudly_without_gpu():
     from sequential_social_dilemma_games_amd.engine import VecEngine
     with pytest.raises(_capi.SsdError):
         VecEngine(0, None, num_envs=1, num_agents=1)
+
+
+def test_python_constants_match_the_header():
+    """The flag / status / error values _capi.py uses are the ones include/ssd.h declares."""
+    import os
+    import re
+    from sequential_social_dilemma_games_amd import _capi
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ssd.h")).read()
+
+    def value(name):
+        m = re.search(r"\b%s\s*=\s*([^,/\n]+)" % name, text)
+        assert m, name
+        expr = m.group(1).strip().replace("u", "")
+        return int(eval(expr))                                   # "1 << 3", "-2", ...
+
+    for name in ("SSD_HOST_PTRS", "SSD_NO_ROTATE", "SSD_OBS_F32", "SSD_ROLLOUT_FUSED"):
+        assert getattr(_capi, name) == value(name), name
+    assert value("SSD_OK") == 0 and value("SSD_E_DEVICE") == -2
+    assert int(re.search(r"#define SSD_ABI_VERSION (\d+)", text).group(1)) == _capi.lib().ssd_abi_version()
