@@ -55,6 +55,10 @@ enum {
     SSD_ROLLOUT_FUSED = 1u << 3, /* ssd_rollout_random only: ONE kernel launch for the whole call -- every env stays in LDS and
                                 registers across its n_steps steps and only the per-step outputs (and, at the end, the state)
                                 go to HBM.  Same results; no per-step launch, state reload or write-back.  uint8 obs only. */
+    SSD_AUTO_RESET = 1u << 4,   /* ssd_step / ssd_step_random: an env whose step reaches the horizon (ssd_set_horizon; its done flags
+                                are 1) starts its next episode in the same launch: MapEnv.reset (map_env.py:214-249) is applied to it
+                                and its observation rows are the reset's (unrotated, :239-240), as if ssd_reset had been called with
+                                the done flags as the mask.  uint8 obs only. */
     SSD_OBS_F32 = 1u << 2    /* obs points at float32 [E,N,V,V,3] instead of uint8: the normalisation of map_env.py:199
                                 fused into the kernel (4x the observation bytes; a separate, slower mode) */
 };

@@ -395,7 +395,9 @@ int ssd_step(ssd_env *env, const int32_t *actions, const uint8_t *order, void *o
              uint32_t flags, void *stream) {
     if (!env) return SSD_E_INVALID;
     if (!actions && env->N > 0) { env->err = "actions is null"; return SSD_E_INVALID; }   // an env without agents has no actions
-    return run(env, ssd::kModeStep, actions, order, nullptr, 0, nullptr, obs, rew, done, 1, flags, stream);
+    if ((flags & SSD_AUTO_RESET) && (flags & SSD_OBS_F32)) { env->err = "SSD_AUTO_RESET writes uint8 observations"; return SSD_E_INVALID; }
+    return run(env, (flags & SSD_AUTO_RESET) ? ssd::kModeStepAuto : ssd::kModeStep, actions, order, nullptr, 0, nullptr, obs, rew, done, 1,
+               flags, stream);
 }
 
 int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, void *obs, int32_t *rew, uint8_t *done,
@@ -403,7 +405,9 @@ int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, voi
     if (!env) return SSD_E_INVALID;
     const int na = env->game == SSD_GAME_HARVEST ? 8 : 9;
     if (num_actions < 1 || num_actions > na) { env->err = "num_actions outside the game's Discrete(n)"; return SSD_E_INVALID; }
-    return run(env, ssd::kModeStep, nullptr, nullptr, nullptr, num_actions, actions_out, obs, rew, done, 1, flags, stream);
+    if ((flags & SSD_AUTO_RESET) && (flags & SSD_OBS_F32)) { env->err = "SSD_AUTO_RESET writes uint8 observations"; return SSD_E_INVALID; }
+    return run(env, (flags & SSD_AUTO_RESET) ? ssd::kModeStepAuto : ssd::kModeStep, nullptr, nullptr, nullptr, num_actions, actions_out, obs,
+               rew, done, 1, flags, stream);
 }
 
 // One chain of a rollout: the launches of steps [0, n_steps) for envs [e_begin, e_end), enqueued on `s`.

@@ -12,7 +12,11 @@ constexpr int kMaxBeamLen = 21;    // 3 rays * beam_len lanes must fit one wavef
 
 constexpr int kListRegs = 3;       // per-lane registers holding the first 192 entries of a static cell list
 
-enum Mode : int32_t { kModeStep = 0, kModeReset = 1, kModeObserve = 2, kModeRollout = 3 };   // rollout: n_steps random-action steps in ONE launch
+enum Mode : int32_t {
+    kModeStep = 0, kModeReset = 1, kModeObserve = 2,
+    kModeRollout = 3,      // n_steps random-action steps in ONE launch
+    kModeStepAuto = 4      // a step that also resets, in the same launch, the envs that reach the horizon (SSD_AUTO_RESET)
+};
 
 // PRNG streams (sequential_social_dilemma_games_amd/prng.py)
 enum Stream : uint32_t {

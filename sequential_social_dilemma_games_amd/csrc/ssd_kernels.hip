@@ -249,6 +249,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     const int n_apple = FAST ? (GAME == 0 ? 155 : 103) : a_n_apple, n_waste = FAST ? 119 : p.n_waste;
     const bool has_order = !FAST && p.order != nullptr, keep_beams = !FAST && p.keep_beams != 0;
     constexpr bool roll = MODE == kModeRollout;                     // many steps per launch, env resident in LDS
+    // A step whose launch also resets the envs that reach the horizon (SSD_AUTO_RESET): the step pass, then -- for those
+    // envs -- a reset pass whose (unrotated) observations replace the step's rows.  Laid out like a plain step.
+    constexpr bool auto_mode = MODE == kModeStepAuto;
+    constexpr bool stepping = MODE == kModeStep || auto_mode;       // the launch takes actions
     uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + (size_t)wv * (512 + 256 + (F32 ? 1024 : 0) + (size_t)A0 + (size_t)A1 +
                                                                             (roll ? 4 : 3) * (size_t)S));
     uint32_t *s_tmp = s_lut + 128;                                  // 64 list entries of scratch (respawn compaction)
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         asm volatile("" ::"s"(p.actions), "s"(p.order), "s"(p.num_actions_random), "s"(p.obs));
         if (GAME == 1) asm volatile("" ::"s"(p.waste_cells), "s"(n_waste), "s"(p.thr_ca), "s"(p.thr_cw), "s"(p.n_thr), "s"(p.rew), "s"(p.done), "s"(p.horizon));
         else asm volatile("" ::"s"(p.thr_h32[0]), "s"(p.thr_h32[1]), "s"(p.thr_h32[2]), "s"(p.thr_h32[3]), "s"(p.thr_h_always));
-        if (mode == kModeStep && is_agent) {
+        if (stepping && is_agent) {
             if (p.num_actions_random <= 0) act_in = p.actions[(size_t)e * N + lane];
             if (has_order) ord_in = p.order[(size_t)e * N + lane];
         }
@@ -364,10 +368,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         }
         bool in_reset = roll && to_reset == 0;
         for (;;) {
-            const bool is_reset = roll ? in_reset : (mode == kModeReset);
-            const bool is_step = roll ? !in_reset : (mode == kModeStep);
+            const bool is_reset = (roll || auto_mode) ? in_reset : (mode == kModeReset);
+            const bool is_step = (roll || auto_mode) ? !in_reset : (mode == kModeStep);
             const size_t slot_en = roll ? (size_t)slot * (size_t)p.E_total * N : 0;     // element offset of the slot in rew / done
-            if (roll) {
+            if (roll || (auto_mode && in_reset)) {
                 // a fresh pass over the resident env: default priority, empty beam / occupancy layers, and on a reset
                 // the grid of reset_map() (:560-564) + custom_reset
                 __builtin_amdgcn_s_setprio(0);
@@ -961,7 +965,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 //   address = base + lin0 | base + lin1 | base + C - lin0 | base + C - lin1,   base = cell - v*(WP+1).
                 uint32_t a_s0 = 0, a_k = 0;
                 if (is_agent) {
-                    a_k = (is_step || p.rotate) ? (orient == 2 ? 0u : orient == 0 ? 1u : orient == 3 ? 2u : 3u) : 0u;
+                    a_k = (is_step || (!roll && !auto_mode && p.rotate)) ? (orient == 2 ? 0u : orient == 0 ? 1u : orient == 3 ? 2u : 3u) : 0u;
                     a_s0 = (uint32_t)((int)cell - v * (WP + 1) + (a_k >= 2 ? (V - 1) * (WP + 1) : 0));
                 }
                 const uint32_t world_lds = (uint32_t)(uintptr_t)(lds_u8 *)s_view;       // LDS byte address of grid cell 0
@@ -1093,6 +1097,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     }
                 }
             }
+            if (auto_mode) {                                  // (done = t >= horizon: the env's next episode starts in this launch)
+                if (is_step && p.horizon > 0 && t >= (uint32_t)p.horizon) { in_reset = true; continue; }
+                break;
+            }
             if (!roll) break;
             if (in_reset) { in_reset = false; continue; }     // the step this reset was due before comes next
             if (++k_step >= p.n_steps) break;
@@ -1124,6 +1132,8 @@ template <int GAME, bool F32, int NA, bool STD, bool FAST>
 static void launch_step(const Params &p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
     if (p.mode == kModeRollout) {
         if constexpr (!F32) hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeRollout, false, NA, STD, FAST>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
+    } else if (p.mode == kModeStepAuto) {
+        if constexpr (!F32) hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStepAuto, false, NA, STD, FAST>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
     } else {
         hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStep, F32, NA, STD, FAST>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
     }
@@ -1131,7 +1141,7 @@ static void launch_step(const Params &p, dim3 grid, dim3 block, size_t lds, hipS
 
 template <int GAME, bool F32>
 static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-    if (p.mode == kModeStep || p.mode == kModeRollout) {
+    if (p.mode == kModeStep || p.mode == kModeRollout || p.mode == kModeStepAuto) {
         // specialised step kernels for the reference's configurations (view 7, beam 5; 5 or 10 agents), and
         // among those the FAST ones for the game's shipped map called in the plain way
         const bool std_view = p.view_len == 7 && p.beam_len == 5;

@@ -128,20 +128,29 @@ class VecEngine(object):
         self.steps_since_full_reset = 0 if mask is None else None
         return obs
 
-    def step(self, actions, order=None, out=None):
+    def step(self, actions, order=None, out=None, auto_reset=False):
         """MapEnv.step (map_env.py:152-212) on every env.  actions: i32 [E,N] (-1 = absent);
-        order: optional u8 [E,N] action-dict order.  Returns (obs, rew, done) device tensors."""
+        order: optional u8 [E,N] action-dict order.  Returns (obs, rew, done) device tensors.
+        auto_reset: envs that reach the horizon (set_horizon) are reset by the same launch, their obs rows are the
+        reset's (SSD_AUTO_RESET; uint8 observations only)."""
         torch, dev = self._torch()
         self._check_tensor(actions, (self.E, self.N), torch.int32, "actions")
         if order is not None:
             self._check_tensor(order, (self.E, self.N), torch.uint8, "order")
         obs, rew, done = out if out is not None else self.alloc_outputs()
         _capi.check(self._L.ssd_step(self._h, self._dp(actions), self._dp(order), self._dp(obs), self._dp(rew),
-                                     self._dp(done), self._obs_flags(obs), self._stream()), self._h)
-        self._count_steps(1)
+                                     self._dp(done), self._obs_flags(obs) | (_capi.SSD_AUTO_RESET if auto_reset else 0),
+                                     self._stream()), self._h)
+        self._count_after_step(auto_reset)
         return obs, rew, done
 
-    def step_random(self, out=None, actions_out=None, num_actions=None):
+    def _count_after_step(self, auto_reset):
+        self._count_steps(1)
+        if auto_reset and self.steps_since_full_reset is not None and getattr(self, "horizon", 0) > 0 \
+                and self.steps_since_full_reset >= self.horizon:
+            self.steps_since_full_reset = 0          # everybody reached the horizon together and was reset by that launch
+
+    def step_random(self, out=None, actions_out=None, num_actions=None, auto_reset=False):
         """One step with uniform random actions drawn on the device (rollout.py:62-70)."""
         if out is not None and out is self._out_cache[0]:                  # same buffers as last time: pointers are known
             obs, rew, done = out
@@ -151,10 +160,11 @@ class VecEngine(object):
             po, pr, pd, fl = self._dp(obs), self._dp(rew), self._dp(done), self._obs_flags(obs)
             self._out_cache = (out, (po, pr, pd, fl))
         na = self.num_actions if num_actions is None else int(num_actions)
-        rc = self._L.ssd_step_random(self._h, na, self._dp(actions_out), po, pr, pd, fl, self._stream())
+        rc = self._L.ssd_step_random(self._h, na, self._dp(actions_out), po, pr, pd,
+                                     fl | (_capi.SSD_AUTO_RESET if auto_reset else 0), self._stream())
         if rc:
             _capi.check(rc, self._h)
-        self._count_steps(1)
+        self._count_after_step(auto_reset)
         return obs, rew, done
 
     def _count_steps(self, n):

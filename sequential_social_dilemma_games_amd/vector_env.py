@@ -39,30 +39,37 @@ class SSDVectorEnv(object):
         self.engine.reset(obs=self._out[0])
         return self._out[0]
 
-    def _auto_reset(self, obs, done):
-        if self.horizon <= 0 or not self.num_agents:
+    # Auto-reset, three ways.  (1) While every env was last reset by the same call (the engine keeps count) they all reach the
+    # horizon on the same step and the host knows which one: nothing to launch until then, a full reset then.  (2) Otherwise
+    # the step launch itself resets the envs that finish (SSD_AUTO_RESET).  (3) float32 observations, which that kernel does
+    # not write: a masked reset launch after every step (a masked reset only touches envs whose flag is set, so no host
+    # synchronisation is needed to decide whether anything finished).
+    def _in_kernel(self):
+        return (self.horizon > 0 and self.num_agents > 0 and self.engine.steps_since_full_reset is None
+                and not self.float32_obs)
+
+    def _auto_reset(self, obs, done, in_kernel):
+        if self.horizon <= 0 or not self.num_agents or in_kernel:
             return
         since = self.engine.steps_since_full_reset
         if since is not None:
-            # every env was last reset by the same call (the engine keeps track): they all reach the horizon on the same
-            # step, the host knows which one, and until then there is nothing to launch
             if since >= self.horizon:
                 self.engine.reset(obs=obs)           # everybody just finished: a full reset, no mask needed
             return
-        # envs at different points of their episodes: every agent of an env finishes together; a masked reset only
-        # touches envs whose flag is set, so no host synchronisation is needed to decide whether anything finished
         self.engine.reset(mask=done[:, 0].contiguous(), obs=obs)
 
     def step(self, actions):
         """actions: int32 [E,N] on the device.  Returns (obs u8, rew i32, done u8) device tensors; envs whose
         episode just ended have been reset and their obs rows replaced by the new episode's first observation."""
-        obs, rew, done = self.engine.step(actions, out=self._out)
-        self._auto_reset(obs, done)
+        in_kernel = self._in_kernel()
+        obs, rew, done = self.engine.step(actions, out=self._out, auto_reset=in_kernel)
+        self._auto_reset(obs, done, in_kernel)
         return obs, rew, done
 
     def step_random(self):
-        obs, rew, done = self.engine.step_random(out=self._out)
-        self._auto_reset(obs, done)
+        in_kernel = self._in_kernel()
+        obs, rew, done = self.engine.step_random(out=self._out, auto_reset=in_kernel)
+        self._auto_reset(obs, done, in_kernel)
         return obs, rew, done
 
     @staticmethod

@@ -519,3 +519,44 @@ def test_vector_env_in_sync_resets_only_on_the_horizon_step():
     venv.engine.reset = real_reset
     venv.try_reset(0)
     assert venv.engine.steps_since_full_reset is None
+
+
+@pytest.mark.parametrize("cfg", [(K.GAME_HARVEST, 5, 41), (K.GAME_CLEANUP, 10, 24), (K.GAME_HARVEST, 7, 19)])
+def test_auto_reset_in_the_step_launch(cfg):
+    """SSD_AUTO_RESET: the step launch resets the envs that reach the horizon; same rewards / dones as a plain step, the
+    observation rows of finished envs are the reset's, the state afterwards is the reset state (oracle: step, then reset
+    with the done flags as the mask).  Envs are put out of phase first; random and explicit actions."""
+    import torch
+    game, N, E = cfg
+    Hz = 6
+    amap = K.HARVEST_MAP if game == K.GAME_HARVEST else K.CLEANUP_MAP
+    eng = VecEngine(game, amap, num_envs=E, num_agents=N, seed=31)
+    ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), seed=31)
+    eng.set_horizon(Hz)
+    out = eng.alloc_outputs()
+    eng.reset(obs=out[0]); ora.reset()
+    rng = np.random.RandomState(1)
+    for _ in range(2):
+        eng.step_random(out=out); ora.step_random()
+    third = (np.arange(E) % 3 == 0).astype(np.uint8)
+    eng.reset(mask=torch.from_numpy(third).cuda(), obs=out[0]); ora.reset(third)
+    na = 8 if game == K.GAME_HARVEST else 9
+    for s in range(17):
+        if s % 2:
+            act = rng.randint(0, na, size=(E, N)).astype(np.int32)
+            obs, rew, done = eng.step(torch.from_numpy(act).cuda(), out=out, auto_reset=True)
+            o_obs, o_rew, _ = ora.step(act)
+        else:
+            obs, rew, done = eng.step_random(out=out, auto_reset=True)
+            _, o_obs, o_rew, _ = ora.step_random()
+        o_done = ora.get_state()["t"] >= Hz
+        if o_done.any():
+            r_obs = ora.reset(o_done.astype(np.uint8))
+            o_obs[o_done] = r_obs[o_done]
+        np.testing.assert_array_equal(done.cpu().numpy(), np.repeat(o_done[:, None], N, 1).astype(np.uint8), err_msg="step %d" % s)
+        np.testing.assert_array_equal(rew.cpu().numpy(), o_rew, err_msg="step %d" % s)
+        np.testing.assert_array_equal(obs.cpu().numpy(), o_obs, err_msg="step %d" % s)
+    a, b = eng.get_state(), ora.get_state()
+    for k in ("world", "pos", "orient", "episode", "t"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert eng.status() == 0
