@@ -314,6 +314,8 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
     p.seed_lo = (uint32_t)cfg->seed; p.seed_hi = (uint32_t)(cfg->seed >> 32); p.env_base = cfg->env_index_base;
     p.n_spawn = (int)spawn_cells.size(); p.n_thr = n_thr;
     p.n_apple = (int)apple_cells.size(); p.n_waste = (int)waste_cells.size();
+    p.n_waste_reset = 0;
+    for (uint8_t ch : reset_world) p.n_waste_reset += ch == 'H';
     const double sp[4] = {0, 0.005, 0.02, 0.05};   // harvest.py:13 SPAWN_PROB
     for (int i = 0; i < 4; ++i) {
         const uint64_t T = cfg->harvest_thresholds ? cfg->harvest_thresholds[i] : threshold(sp[i]);
@@ -542,7 +544,7 @@ int ssd_get_waste_count(ssd_env *env, uint32_t *waste_count) {
     SSD_HIP(env, hipDeviceSynchronize());
     std::vector<uint4> hdr(env->E);
     SSD_HIP(env, hipMemcpy(hdr.data(), env->p.hdr, hdr.size() * sizeof(uint4), hipMemcpyDeviceToHost));
-    for (int e = 0; e < env->E; ++e) waste_count[e] = hdr[e].w;
+    for (int e = 0; e < env->E; ++e) waste_count[e] = hdr[e].w & 0xFFFFu;   // (upper half: the grid's current count, kernel-internal)
     return SSD_OK;
 }
 
@@ -595,10 +597,16 @@ int ssd_set_state(ssd_env *env, const int8_t *world, const int8_t *beam, const i
         }
         SSD_HIP(env, hipMemcpy(env->p.agents, ag.data(), ag.size() * 4, hipMemcpyHostToDevice));
     }
-    if (episode || t) {
+    const bool recount = world && env->game == SSD_GAME_CLEANUP;      // the kernel keeps the grid's 'H' count in hdr.w
+    if (episode || t || recount) {
         std::vector<uint4> hdr(E);
         SSD_HIP(env, hipMemcpy(hdr.data(), env->p.hdr, hdr.size() * sizeof(uint4), hipMemcpyDeviceToHost));
         for (int e = 0; e < E; ++e) {
+            if (recount) {
+                uint32_t n = 0;
+                for (int i = 0; i < hw; ++i) n += world[(size_t)e * hw + i] == 'H';
+                hdr[e].w = (hdr[e].w & 0xFFFFu) | (n << 16);
+            }
             if (t) hdr[e].y = t[e];
             if (episode) {
                 hdr[e].z = episode[e];

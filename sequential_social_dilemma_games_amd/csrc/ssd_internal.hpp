@@ -40,6 +40,7 @@ struct Params {
     uint32_t v_magic16;            // ceil(2^16 / V): pp / V == (pp * v_magic16) >> 16 for pp < V*V, V <= 31
     uint32_t seed_lo, seed_hi, env_base;
     int32_t n_spawn, n_thr, n_apple, n_waste;
+    int32_t n_waste_reset;         // Cleanup: number of 'H' cells in reset_world
     // engine state in HBM
     uint8_t *world;                // [E][S]  ASCII cells
     uint8_t *beam;                 // [E][S]  beam overlay (keep_beams only), 0 = none

@@ -345,6 +345,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // The grid, agents and header go back to HBM once per launch: right after the respawn of a step / reset launch,
         // after the last step of a rollout launch.
         uint32_t waste_last = 0;
+        // Cleanup keeps the number of 'H' cells of the stored grid in the upper half of hdr.w (the lower half is the count
+        // the last spawn pass used, ssd_get_waste_count): a step only changes it by the cells its CLEAN beams clean and the
+        // one waste cell it may spawn, so compute_permitted_area (cleanup.py:173-179) need not recount the grid.
+        uint32_t waste_cur = GAME == 1 ? rfl(hdr.w) >> 16 : 0u;
         auto write_state = [&]() {
             uint8_t *gw = a_world + (size_t)e * S;
             for (int i = lane * 16; i < S; i += 64 * 16) {
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     *reinterpret_cast<uint4 *>(p.beam + (size_t)e * S + i) = *reinterpret_cast<const uint4 *>(s_beam + i);
             }
             if (is_agent) a_agents[(size_t)e * N + lane] = cell | (orient << 16);
-            if (lane == 0) a_hdr[e] = make_uint4(key, t, episode, waste_last);
+            if (lane == 0) a_hdr[e] = make_uint4(key, t, episode, waste_last | (waste_cur << 16));
             if (status && lane == 0) atomicOr(p.status, status);
         };
         // ---- One pass = one reset or one step of the env.  A step / reset / observe launch makes one pass.  A rollout
@@ -383,9 +387,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 }
                 wave_sync();
             }
+            uint32_t cleaned = 0;                                 // 'H' cells turned into 'R' by this pass's CLEAN beams
             if (is_reset) {
                 // ---- MapEnv.reset (map_env.py:214-249) ----
                 episode += 1; t = 0;
+                waste_cur = (uint32_t)p.n_waste_reset;            // the grid is reset_world again
                 key = env_key(p.seed_lo, p.seed_hi, p.env_base + (uint32_t)e, episode);
                 // the grid loaded above is reset_map (:560-564) + custom_reset of the base map
                 // setup_agents (harvest.py:46-55 / cleanup.py:118-130): spawn_point (map_env.py:651-662) takes
@@ -699,6 +705,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                             s_beam[cidx] = clean ? 'C' : 'F';                           // :624,:636 firing_points
                             if (clean && wch == 'H') s_world[cidx] = 'R';               // :625-634 cell_types ['H'] -> ['R']
                         }
+                        if (GAME == 1) cleaned += (uint32_t)__builtin_popcountll(ballot(covered & clean & (wch == 'H')));
                         // agent.py:166-168 hit('F'): the last-index agent (:603) on a cell where a FIRE ray stopped loses 50 per ray
                         uint64_t hits = ballot(stopper & !clean & (och != 0) & (kk == fs) & (fs < ff));
                         const bool top = __builtin_amdgcn_inverse_ballot_w64(highest);
@@ -740,6 +747,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                         s_beam[cidx] = clean ? 'C' : 'F';                               // :624,:636 firing_points
                         if (clean && wch == 'H') s_world[cidx] = 'R';                   // :625-634 cell_types ['H'] -> ['R']
                     }
+                    cleaned += (uint32_t)__builtin_popcountll(ballot(inray & (kk < len) & clean & (wch == 'H')));
                     if (fire) {                                                         // agent.py:166-168 hit('F'): -50
                         for (int q2 = 0; q2 < 3; ++q2) {
                             const uint32_t f2 = (uint32_t)(mf >> (q2 * L)) & rmask, s2 = (uint32_t)(ms >> (q2 * L)) & rmask;
@@ -844,12 +852,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 } else {
                     // cleanup.py:113-116: compute_probabilities (:156-171) from the current waste count, then
                     // spawn_apples_and_waste (:132-154).  Thresholds come from a host-computed table.
-                    uint32_t nh = 0;
-                    for (int i = lane * 16; i < S; i += 64 * 16) {
-                        const uint4 qd = *reinterpret_cast<const uint4 *>(s_world + i);
-                        nh += count_bytes_eq(qd.x, 'H') + count_bytes_eq(qd.y, 'H') + count_bytes_eq(qd.z, 'H') + count_bytes_eq(qd.w, 'H');
-                    }
-                    nh = wave_sum_u32(nh);                                              // compute_permitted_area (:173-179)
+                    uint32_t nh = waste_cur - cleaned;                                  // compute_permitted_area (:173-179), kept incrementally
                     waste_count = nh;
                     nh = nh < (uint32_t)p.n_thr ? nh : (uint32_t)p.n_thr - 1;
                     const uint64_t thr_a = p.thr_ca[nh], thr_w = p.thr_cw[nh];
@@ -902,6 +905,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 for (int j = kListRegs; j < a_iters; ++j)
                     if ((spawn_bits >> j) & 1) s_world[a_apple_cells[lane + 64 * j] & 0xFFFFu] = 'A';
                 if (waste_cell != 0xFFFFFFFFu) s_world[waste_cell] = 'H';               // may land under an agent
+                if (GAME == 1) waste_cur = waste_count + (waste_cell != 0xFFFFFFFFu ? 1u : 0u);
                 wave_sync();
 
                 SSD_STAMP(5);   // respawn
