@@ -46,7 +46,20 @@ def main():
         eng.step_random(out=out)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("batched API: %7.2f M agent-env-steps/s (4096 envs x 5 agents x %d steps)" % (4096 * 5 * horizon / dt / 1e6, horizon))
+    print("batched API: %7.2f M agent-env-steps/s (4096 envs x 5 agents x %d steps, one Python call per step)"
+          % (4096 * 5 * horizon / dt / 1e6, horizon))
+
+    # --- the whole rollout as one library call (rollout.py:58-70): step launches enqueued from C, then one fused launch
+    ring = tuple(t.unsqueeze(0) for t in out)     # 1 output slot: every step overwrites the same buffers
+    for fused in (False, True):
+        eng.rollout_random(horizon, *ring, reset_every=horizon, fused=fused)      # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.rollout_random(horizon, *ring, reset_every=horizon, fused=fused)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print("rollout API: %7.2f M agent-env-steps/s (%s)" % (4096 * 5 * horizon / dt / 1e6,
+              "ONE kernel launch for the whole rollout" if fused else "one kernel launch per step and env range"))
 
 
 if __name__ == "__main__":
