@@ -80,16 +80,9 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Full-wave reductions: inclusive scan inside each row of 16 lanes with DPP row_shr (VALU latency,
-// no LDS crossbar), then the four row totals (lanes 15/31/47/63) are combined on the scalar unit.
+// Full-wave reduction: inclusive scan inside each row of 16 lanes with DPP row_shr (VALU latency,
+// no LDS crossbar), then the four row results (lanes 15/31/47/63) are combined on the scalar unit.
 #define SSD_DPP(old, v, ctrl, bc) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(v), ctrl, 0xF, 0xF, bc))
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-    v += SSD_DPP(0, v, 0x111, true);   // row_shr:1, out-of-row lanes read 0
-    v += SSD_DPP(0, v, 0x112, true);   // row_shr:2
-    v += SSD_DPP(0, v, 0x114, true);   // row_shr:4
-    v += SSD_DPP(0, v, 0x118, true);   // row_shr:8
-    return rl(v, 15) + rl(v, 31) + rl(v, 47) + rl(v, 63);
-}
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     v = umin(v, SSD_DPP(0xFFFFFFFFu, v, 0x111, false));   // out-of-row lanes keep `old` = identity
     v = umin(v, SSD_DPP(0xFFFFFFFFu, v, 0x112, false));
@@ -151,12 +144,6 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
     uint32_t m = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
     return (m >> 7) * 0xFFu;
 }
-// number of bytes of x equal to ch
-__device__ __forceinline__ uint32_t count_bytes_eq(uint32_t x, uint32_t ch) {
-    const uint32_t y = x ^ (ch * 0x01010101u);
-    return (uint32_t)__builtin_popcount(~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u);
-}
-
 // Per-phase cycle stamps for tools/phase_profile.py: compiled only into the diagnostic library
 // (make stamps); the product build contains no stamp code.
 #ifdef SSD_STAMPS
