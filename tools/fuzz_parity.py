@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Randomised parity fuzz (GPU box; not part of the suite): random wall-closed maps, agent counts, views, beam lengths and
+env counts, stepped four ways -- call by call with random action subsets / orders, ssd_rollout_random as chains, as the
+fused rollout kernel, and with SSD_AUTO_RESET -- against the C oracle, bit for bit.
+
+    python tools/fuzz_parity.py [n_configs] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import torch  # noqa: E402
+import golden_util as G  # noqa: E402
+from oracle import pyoracle  # noqa: E402
+from sequential_social_dilemma_games_amd import constants as K  # noqa: E402
+from sequential_social_dilemma_games_amd.engine import VecEngine  # noqa: E402
+from test_hip_parity import _random_map  # noqa: E402
+
+
+def check_state(eng, ora, where):
+    a, b = eng.get_state(), ora.get_state()
+    for k in ("world", "pos", "orient", "episode", "t"):
+        assert np.array_equal(a[k], b[k]), "%s differs (%s)" % (k, where)
+
+
+def one(rng, idx):
+    game = int(rng.randint(0, 2))
+    H, W = int(rng.randint(4, 26)), int(rng.randint(4, 31))
+    free = (H - 2) * (W - 2)
+    N = int(rng.randint(1, min(14, max(2, free // 3))))
+    v, L = int(rng.randint(0, 11)), int(rng.randint(1, 9))
+    E = int(rng.randint(1, 70))
+    amap = _random_map(rng, H, W, game, n_spawn=N + int(rng.randint(0, 4)))
+    keep = bool(rng.randint(0, 2))
+    seed = int(rng.randint(0, 2 ** 31))
+    tag = "cfg %d: game %d %dx%d N=%d v=%d L=%d E=%d keep=%d seed=%d" % (idx, game, H, W, N, v, L, E, keep, seed)
+    try:
+        eng = VecEngine(game, amap, num_envs=E, num_agents=N, view_len=v, beam_len=L, seed=seed, keep_beams=keep)
+    except Exception as ex:                                   # e.g. LDS budget: not a parity matter
+        print(tag, "-> skipped:", str(ex)[:80])
+        return
+    ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), view_len=v, beam_len=L, seed=seed)
+    V, na = 2 * v + 1, (8 if game == K.GAME_HARVEST else 9)
+    assert np.array_equal(eng.reset_host(), ora.reset()), tag + " reset"
+    # (1) call by call, explicit subsets / orders every other step
+    for s in range(12):
+        if s % 2:
+            act = rng.randint(0, na, size=(E, N)).astype(np.int32)
+            order = np.full((E, N), 0xFF, np.uint8)
+            for e in range(E):
+                k = rng.randint(0, N + 1)
+                perm = rng.permutation(N)[:k]
+                order[e, :k] = perm
+                act[e, np.setdiff1d(np.arange(N), perm)] = -1
+            obs, rew, _ = eng.step_host(act, order)
+            o_obs, o_rew, _ = ora.step(act, order)
+        else:
+            _, obs, rew, _ = eng.step_random_host()
+            _, o_obs, o_rew, _ = ora.step_random()
+        assert np.array_equal(rew, o_rew) and np.array_equal(obs, o_obs), tag + " step %d" % s
+    check_state(eng, ora, tag + " after steps")
+    # (2) rollout as chains, (3) fused
+    ring = 3
+    obs = torch.zeros((ring, E, N, V, V, 3), dtype=torch.uint8, device="cuda")
+    rew = torch.zeros((ring, E, N), dtype=torch.int32, device="cuda")
+    done = torch.zeros((ring, E, N), dtype=torch.uint8, device="cuda")
+    step0 = 0
+    for fused in (False, True):
+        n, every = int(rng.randint(1, 14)), int(rng.randint(1, 8))
+        eng.set_rollout_chains(int(rng.randint(1, 5)))
+        want = {}
+        for k in range(step0, step0 + n):
+            if k % every == 0:
+                ora.reset()
+            _, o_obs, o_rew, _ = ora.step_random()
+            want[k] = (o_obs, o_rew)
+        eng.rollout_random(n, obs, rew, done, reset_every=every, step0=step0, fused=fused)
+        g_obs, g_rew = obs.cpu().numpy(), rew.cpu().numpy()
+        for k in range(max(step0, step0 + n - ring), step0 + n):
+            assert np.array_equal(g_obs[k % ring], want[k][0]) and np.array_equal(g_rew[k % ring], want[k][1]), \
+                tag + " rollout fused=%d step %d" % (fused, k)
+        check_state(eng, ora, tag + " after rollout fused=%d" % fused)
+        step0 += n
+    # (4) auto-reset in the step launch, envs out of phase
+    Hz = int(rng.randint(2, 7))
+    eng.set_horizon(Hz)
+    out = eng.alloc_outputs()
+    part = (rng.rand(E) < 0.5).astype(np.uint8)
+    eng.reset(mask=torch.from_numpy(part).cuda(), obs=out[0]); ora.reset(part)
+    for s in range(9):
+        o, r, d = eng.step_random(out=out, auto_reset=True)
+        _, o_obs, o_rew, _ = ora.step_random()
+        o_done = ora.get_state()["t"] >= Hz
+        if o_done.any():
+            r_obs = ora.reset(o_done.astype(np.uint8))
+            o_obs[o_done] = r_obs[o_done]
+        assert np.array_equal(d.cpu().numpy(), np.repeat(o_done[:, None], N, 1).astype(np.uint8)), tag + " auto done %d" % s
+        assert np.array_equal(r.cpu().numpy(), o_rew) and np.array_equal(o.cpu().numpy(), o_obs), tag + " auto step %d" % s
+    check_state(eng, ora, tag + " after auto-reset steps")
+    assert eng.status() == 0, tag + " status"
+    eng.close()
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    for i in range(n):
+        one(rng, i)
+        if i % 20 == 19:
+            print("%d configurations ok" % (i + 1), flush=True)
+    print("fuzz ok: %d configurations" % n)
+
+
+if __name__ == "__main__":
+    main()
