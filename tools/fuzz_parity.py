@@ -28,11 +28,14 @@ def check_state(eng, ora, where):
 
 def one(rng, idx):
     game = int(rng.randint(0, 2))
-    H, W = int(rng.randint(4, 26)), int(rng.randint(4, 31))
+    big = os.environ.get("FUZZ_BIG") == "1"               # the limits of the ABI: 64 agents, 4096 cells, 31 x 31 views, beams of 21
+    H, W = (int(rng.randint(4, 65)), int(rng.randint(4, 65))) if big else (int(rng.randint(4, 26)), int(rng.randint(4, 31)))
+    if H * W > 4096:
+        W = 4096 // H
     free = (H - 2) * (W - 2)
-    N = int(rng.randint(1, min(14, max(2, free // 3))))
-    v, L = int(rng.randint(0, 11)), int(rng.randint(1, 9))
-    E = int(rng.randint(1, 70))
+    N = int(rng.randint(1, min(65 if big else 14, max(2, free // 3))))
+    v, L = (int(rng.randint(0, 16)), int(rng.randint(1, 22))) if big else (int(rng.randint(0, 11)), int(rng.randint(1, 9)))
+    E = int(rng.randint(1, 40 if big else 70))
     amap = _random_map(rng, H, W, game, n_spawn=N + int(rng.randint(0, 4)))
     keep = bool(rng.randint(0, 2))
     seed = int(rng.randint(0, 2 ** 31))
