@@ -126,14 +126,18 @@ def main():
     assert (start, count) == (rank * E, E)
     out = eng.alloc_outputs(float32=args.obs_f32)
     do_gather = bool(args.gather and dist is not None)
-    GR = 8                                         # --gather: steps per collective (one RCCL all-gather moves GR steps' outputs)
+    GR = 32                                        # --gather: steps per collective (one RCCL all-gather moves GR steps' outputs)
     gring = gbuf = None
     if do_gather:                                  # the batched tensors every rank ends up with: [world, GR, E, ...]
-        gring = (torch.empty((GR,) + tuple(out[0].shape), dtype=out[0].dtype, device=out[0].device),
-                 torch.empty((GR,) + tuple(out[1].shape), dtype=torch.int32, device=out[1].device),
-                 torch.empty((GR,) + tuple(out[2].shape), dtype=torch.uint8, device=out[2].device))
-        gbuf = (torch.empty((world,) + tuple(gring[0].shape), dtype=gring[0].dtype, device=out[0].device),
-                torch.empty((world,) + tuple(gring[1].shape), dtype=torch.int32, device=out[1].device))
+        # two rings: while the collective of one is in flight on its own stream, the rollout fills the other
+        grings = [(torch.empty((GR,) + tuple(out[0].shape), dtype=out[0].dtype, device=out[0].device),
+                   torch.empty((GR,) + tuple(out[1].shape), dtype=torch.int32, device=out[1].device),
+                   torch.empty((GR,) + tuple(out[2].shape), dtype=torch.uint8, device=out[2].device)) for _ in range(2)]
+        gbuf = (torch.empty((world,) + tuple(grings[0][0].shape), dtype=grings[0][0].dtype, device=out[0].device),
+                torch.empty((world,) + tuple(grings[0][1].shape), dtype=torch.int32, device=out[1].device))
+        comm_stream = torch.cuda.Stream()
+        ring_ready = [torch.cuda.Event() for _ in range(2)]     # the rollout has filled ring i
+        ring_free = [torch.cuda.Event() for _ in range(2)]      # the collective has read ring i
 
     def one_step(k):
         if k % HORIZON == 0:
@@ -154,8 +158,12 @@ def main():
         if do_gather:
             # GR steps into a ring of GR slots, then ONE RCCL all-gather of the ring (obs) and one of the rewards over xGMI:
             # every rank ends up with all ranks' outputs of those steps
+            main = torch.cuda.current_stream()
             for c0 in range(k0, k0 + n, GR):
                 m = min(GR, k0 + n - c0)
+                i = (c0 // GR) % 2
+                gring = grings[i]
+                main.wait_event(ring_free[i])          # (no-op until the event has been recorded once)
                 if use_rollout:
                     eng.rollout_random(m, gring[0], gring[1], gring[2], reset_every=HORIZON, step0=c0)
                 else:
@@ -163,8 +171,13 @@ def main():
                         if k % HORIZON == 0:
                             eng.reset(obs=gring[0][k % GR])
                         eng.step_random(out=(gring[0][k % GR], gring[1][k % GR], gring[2][k % GR]))
-                parallel.all_gather_ring(dist, gring[0], world, out=gbuf[0])
-                parallel.all_gather_ring(dist, gring[1], world, out=gbuf[1])
+                ring_ready[i].record(main)
+                with torch.cuda.stream(comm_stream):   # the collectives overlap the next chunk's steps
+                    comm_stream.wait_event(ring_ready[i])
+                    parallel.all_gather_ring(dist, gring[0], world, out=gbuf[0])
+                    parallel.all_gather_ring(dist, gring[1], world, out=gbuf[1])
+                    ring_free[i].record(comm_stream)
+            main.wait_stream(comm_stream)              # the K steps are not done before their last collective is
         elif use_rollout:
             for c0 in range(k0, k0 + n, 1000):
                 eng.rollout_random(min(1000, k0 + n - c0), ring[0], ring[1], ring[2], reset_every=HORIZON, step0=c0)
@@ -225,7 +238,7 @@ def main():
             "config": {"workload": "%s %dx%d, %d agents, %d envs per GPU, uniform random actions, reset every %d steps"
                                    % (args.game, eng.H, eng.W, n_agents, E, HORIZON),
                        "envs_per_gpu": E, "agents": n_agents, "obs": ("float32" if args.obs_f32 else "uint8") + " [E,N,15,15,3]", "launches_per_step": chains, "enqueue": ("ssd_rollout_random, %d chain(s) of %d envs" % (chains, E // chains)) if use_rollout else "one call per step",
-                       "gather": ("one RCCL all-gather of obs and one of rewards per %d steps" % GR) if do_gather else False, "parallelism": "env-shard x%d" % world},
+                       "gather": ("one RCCL all-gather of obs and one of rewards per %d steps, overlapped with the next %d steps" % (GR, GR)) if do_gather else False, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "ssd::ssd_env_kernel<%d, 0, %s, ...>" % (game, "true" if args.obs_f32 else "false"), "bytes_per_env_step": bytes_env,
