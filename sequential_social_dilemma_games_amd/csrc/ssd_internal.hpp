@@ -10,7 +10,8 @@ constexpr int kMaxAgents = 64;     // lanes = agents in the move / beam phases
 constexpr int kMaxCells = 4096;    // H*W, bounded by the u64 per-lane spawn bitmask and by LDS (grid indices stay below 2^16)
 constexpr int kMaxBeamLen = 21;    // 3 rays * beam_len lanes must fit one wavefront
 
-constexpr int kListRegs = 3;       // per-lane registers holding the first 192 entries of a static cell list
+constexpr int kListRegsHarvest = 3, kListRegsCleanup = 8;   // per-lane registers holding the first 192 / 512 entries of a static
+                                   // cell list (only as many as the list needs are touched: the loops skip on 64 * j >= n)
 
 enum Mode : int32_t {
     kModeStep = 0, kModeReset = 1, kModeObserve = 2,

@@ -231,6 +231,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     const int S = FAST ? (GAME == 0 ? 720 : 640) : p.S;
     const int A0 = FAST ? (GAME == 0 ? 336 : 192) : p.A0, A1 = FAST ? (GAME == 0 ? 320 : 176) : p.A1;
     const int N = NA > 0 ? NA : p.N;
+    // List registers per lane (64 * kLR entries of a static cell list live in registers, the rest is read from memory when
+    // needed).  Measured: 8 pays for Cleanup's long lists (48x36 map: 412 apple / 476 waste points, -4 % per step, -10 %
+    // fused), 3 is better for Harvest (25x38 map, 262 apple points: 8 costs +4 % per step).
+    constexpr int kLR = GAME == 1 ? kListRegsCleanup : kListRegsHarvest;
     // sizes of the map's cell lists (FAST: the shipped maps' -- launch_game() checks them): lets the compiler drop the
     // unused third list register of Cleanup's 103 apple / 119 waste points
     const int n_apple = FAST ? (GAME == 0 ? 155 : 103) : a_n_apple, n_waste = FAST ? 119 : p.n_waste;
@@ -279,12 +283,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         const bool obs_f32 = F32 && a_obs;
         float4 flut = make_float4(0.f, 0.f, 0.f, 0.f);
         if (obs_f32) flut = reinterpret_cast<const float4 *>(p.f32lut)[lane];
-        // static cell lists of the map: the first 64*kListRegs entries live in registers
-        uint32_t alist[kListRegs], wlist[kListRegs];
+        // static cell lists of the map: the first 64 * kLR entries live in registers
+        uint32_t alist[kLR], wlist[kLR];
 #pragma unroll
-        for (int j = 0; j < kListRegs; ++j) {
+        for (int j = 0; j < kLR; ++j) {
             const int idx = lane + 64 * j;
-            alist[j] = (mode != kModeObserve && idx < n_apple) ? a_apple_cells[idx] : 0u;
+            alist[j] = 0u;
+            if (kLR <= 3 || 64 * j < n_apple) alist[j] = (mode != kModeObserve && idx < n_apple) ? a_apple_cells[idx] : 0u;
         }
         // The other kernel arguments are fetched lazily by default, one scalar-cache round trip per basic block that needs
         // one.  Pin what the rest of the prologue and the respawn need into SGPRs here -- the loads above are in flight --
@@ -298,9 +303,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             if (has_order) ord_in = p.order[(size_t)e * N + lane];
         }
 #pragma unroll
-        for (int j = 0; j < kListRegs; ++j) {
+        for (int j = 0; j < kLR; ++j) {
             const int idx = lane + 64 * j;
-            wlist[j] = (GAME == 1 && mode != kModeObserve && idx < n_waste) ? p.waste_cells[idx] : 0u;
+            wlist[j] = 0u;
+            if (GAME == 1 && 64 * j < n_waste) wlist[j] = (mode != kModeObserve && idx < n_waste) ? p.waste_cells[idx] : 0u;
         }
         uint32_t key = rfl(hdr.x), t = rfl(hdr.y), episode = rfl(hdr.z);
         s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b;
@@ -792,23 +798,27 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     // Pass 1 (cheap): which list entries are candidates at all -- a cell without an apple (:88; "nobody stands
                     // on it" is checked for the few winners only).  The unused entries of the list registers are 0 = grid
                     // cell 0, a wall, and an apple point is never a wall: "neither 'A' nor '@'" needs no validity test.
-                    bool el[kListRegs];
-                    uint64_t em[kListRegs];
+                    bool el[kLR];
+                    uint64_t em[kLR];
                     int total = 0;
 #pragma unroll
-                    for (int j = 0; j < kListRegs; ++j) {
-                        const uint8_t ch = s_world[alist[j] & 0xFFFFu];
-                        el[j] = (ch != 'A') & (ch != '@');
-                        em[j] = ballot(el[j]);
-                        total += __builtin_popcountll(em[j]);
+                    for (int j = 0; j < kLR; ++j) {
+                        el[j] = false; em[j] = 0;
+                        if (kLR <= 3 || 64 * j < n_apple) {                             // (wave-uniform: skips unused list registers)
+                            const uint8_t ch = s_world[alist[j] & 0xFFFFu];
+                            el[j] = (ch != 'A') & (ch != '@');
+                            em[j] = ballot(el[j]);
+                            total += __builtin_popcountll(em[j]);
+                        }
                     }
-                    if (a_iters <= kListRegs && total <= 64) {
-                        // Usual case: at most 64 candidates among the (up to 192) apple points.  Compact them through
+                    if (a_iters <= kLR && total <= 64) {
+                        // Usual case: at most 64 candidates among the (up to 512) apple points.  Compact them through
                         // 128 B of LDS scratch so that ONE pass of lanes does the stencil + draw instead of three.
                         if (total) {
                             int base = 0;
 #pragma unroll
-                            for (int j = 0; j < kListRegs; ++j) {
+                            for (int j = 0; j < kLR; ++j) {
+                                if (kLR > 3 && 64 * j >= n_apple) continue;
                                 const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(em[j] >> 32),
                                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)em[j], 0u));
                                 if (el[j]) s_tmp[slot] = alist[j];
@@ -824,11 +834,12 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     } else {
                         // general form: every lane evaluates its own list entries
 #pragma unroll
-                        for (int j = 0; j < kListRegs; ++j) {
+                        for (int j = 0; j < kLR; ++j) {
+                            if (kLR > 3 && 64 * j >= n_apple) continue;
                             const uint32_t c = el[j] ? alist[j] : safe;
                             spawn_bits |= (el[j] & wins(c) & (s_occ[c & 0xFFFFu] == 0)) ? bit(j) : 0ull;
                         }
-                        for (int j = kListRegs; j < a_iters; ++j) {
+                        for (int j = kLR; j < a_iters; ++j) {
                             const int idx = lane + 64 * j;
                             const bool valid = idx < n_apple;
                             const uint32_t c = valid ? a_apple_cells[idx] : safe;
@@ -851,9 +862,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     };
                     if (thr_a) {                                                        // (density >= thresholdDepletion: nothing grows, :161-163)
 #pragma unroll
-                        for (int j = 0; j < kListRegs; ++j)
+                        for (int j = 0; j < kLR; ++j)
                             if (64 * j < n_apple) apple(j, alist[j], lane + 64 * j < n_apple);   // (wave-uniform: skips unused list registers)
-                        for (int j = kListRegs; j < a_iters; ++j) {
+                        for (int j = kLR; j < a_iters; ++j) {
                             const int idx = lane + 64 * j;
                             apple(j, idx < n_apple ? a_apple_cells[idx] : 0u, idx < n_apple);
                         }
@@ -874,9 +885,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                         };
                         const int w_iters = (n_waste + 63) >> 6;
 #pragma unroll
-                        for (int j = 0; j < kListRegs; ++j)
+                        for (int j = 0; j < kLR; ++j)
                             if (64 * j < n_waste) waste(wlist[j], lane + 64 * j < n_waste);
-                        for (int j = kListRegs; j < w_iters; ++j) {
+                        for (int j = kLR; j < w_iters; ++j) {
                             const int idx = lane + 64 * j;
                             waste(idx < n_waste ? p.waste_cells[idx] : 0u, idx < n_waste);
                         }
@@ -887,9 +898,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 }
                 wave_sync();                                                            // counts use the pre-spawn map (harvest.py:73)
 #pragma unroll
-                for (int j = 0; j < kListRegs; ++j)
-                    if ((spawn_bits >> j) & 1) s_world[alist[j] & 0xFFFFu] = 'A';
-                for (int j = kListRegs; j < a_iters; ++j)
+                for (int j = 0; j < kLR; ++j)
+                    if ((kLR <= 3 || 64 * j < n_apple) && ((spawn_bits >> j) & 1)) s_world[alist[j] & 0xFFFFu] = 'A';
+                for (int j = kLR; j < a_iters; ++j)
                     if ((spawn_bits >> j) & 1) s_world[a_apple_cells[lane + 64 * j] & 0xFFFFu] = 'A';
                 if (waste_cell != 0xFFFFFFFFu) s_world[waste_cell] = 'H';               // may land under an agent
                 if (GAME == 1) waste_cur = waste_count + (waste_cell != 0xFFFFFFFFu ? 1u : 0u);

@@ -21,9 +21,11 @@ NAMES = ["load state", "actions+move", "consume+occ", "beams", "respawn", "write
 
 
 def main():
-    game = K.GAME_CLEANUP if (len(sys.argv) > 1 and sys.argv[1] == "cleanup") else K.GAME_HARVEST
+    which = sys.argv[1] if len(sys.argv) > 1 else "harvest"
+    game = K.GAME_CLEANUP if which.startswith("cleanup") else K.GAME_HARVEST
     E = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-    eng = VecEngine(game, None, num_envs=E, num_agents=5, seed=0)
+    amap, n_agents = {"cleanup48x36": (K.cleanup_map_48x36(), 10), "harvest25x38": (K.harvest_map_25x38(), 5)}.get(which, (None, 5))
+    eng = VecEngine(game, amap, num_envs=E, num_agents=n_agents, seed=0)
     out = eng.alloc_outputs()
     eng.reset(obs=out[0])
     for _ in range(200):
