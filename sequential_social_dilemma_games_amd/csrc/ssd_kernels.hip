@@ -207,9 +207,17 @@ __host__ int envs_per_block(const Params &p, bool f32) {
 // constants (harvest.py:11,15; cleanup.py:11-12,22).  Fixing them lets the compiler unroll the agent loops, fold the
 // window arithmetic and address agents' lanes by immediate: 14.3 -> 12.6 us per 4096-env step (N, V, L fixed).
 // NA = 0 / STD = false is the fully general kernel.
-// FAST additionally fixes the map to the game's shipped one (Harvest 16x38, Cleanup 25x18) and the call to its plain
+// FAST (1, 2) additionally fixes the map to a known one (kFastMap: the shipped maps, the enlarged ones) and the call to its plain
 // form (index action order, beams not kept): another 3.8 %.
-template <int GAME, int MODE, bool F32, int NA, bool STD, bool FAST>
+// Grid layout constants of the maps the FAST kernels are compiled for (view_len 7): FAST = 1 the game's shipped map
+// (Harvest 16x38, Cleanup 25x18), FAST = 2 the enlarged maps of BASELINE.json's configurations (Harvest 25x38, Cleanup
+// 48x36; constants.py builds them by the rule of SURVEY.md 8d).  launch_game() checks every one of these numbers.
+struct FastMap { int H, W, WP, S, A0, A1, n_apple, n_waste; };
+constexpr FastMap kFastMap[2][3] = {
+    {{0, 0, 0, 0, 0, 0, 0, 0}, {16, 38, 45, 720, 336, 320, 155, 0}, {25, 38, 45, 1136, 336, 320, 252, 0}},
+    {{0, 0, 0, 0, 0, 0, 0, 0}, {25, 18, 25, 640, 192, 176, 103, 119}, {48, 36, 43, 2064, 320, 304, 412, 476}}};
+
+template <int GAME, int MODE, bool F32, int NA, bool STD, int FAST>
 // The leading arguments repeat the Params fields the first global loads need (14 dwords).  Built with
 // -mllvm -amdgpu-kernarg-preload-count=14 the command processor delivers them in SGPRs when the wave starts, so the
 // loads of the env's state go out without first waiting ~0.3 us for a scalar load of the kernel arguments.
@@ -226,10 +234,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     // the wave index and everything derived from it (env index, LDS region, global offsets) is wave-uniform:
     // say so, and the per-env address arithmetic runs on the scalar unit instead of as 64-bit VALU multiplies
     const int wv = (int)rfl((uint32_t)tid >> 6);
-    // FAST: the shipped maps with view_len 7 -- Harvest 16 x (38 + 7), Cleanup 25 x (18 + 7)
-    const int WP = FAST ? (GAME == 0 ? 45 : 25) : p.WP;
-    const int S = FAST ? (GAME == 0 ? 720 : 640) : p.S;
-    const int A0 = FAST ? (GAME == 0 ? 336 : 192) : p.A0, A1 = FAST ? (GAME == 0 ? 320 : 176) : p.A1;
+    // FAST: the layout constants of a known map (kFastMap) instead of kernel arguments
+    constexpr FastMap fm = kFastMap[GAME][FAST];
+    const int WP = FAST ? fm.WP : p.WP;
+    const int S = FAST ? fm.S : p.S;
+    const int A0 = FAST ? fm.A0 : p.A0, A1 = FAST ? fm.A1 : p.A1;
     const int N = NA > 0 ? NA : p.N;
     // List registers per lane (64 * kLR entries of a static cell list live in registers, the rest is read from memory when
     // needed).  Measured: 8 pays for Cleanup's long lists (48x36 map: 412 apple / 476 waste points, -4 % per step, -10 %
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     constexpr int kLR = GAME == 1 ? kListRegsCleanup : kListRegsHarvest;
     // sizes of the map's cell lists (FAST: the shipped maps' -- launch_game() checks them): lets the compiler drop the
     // unused third list register of Cleanup's 103 apple / 119 waste points
-    const int n_apple = FAST ? (GAME == 0 ? 155 : 103) : a_n_apple, n_waste = FAST ? 119 : p.n_waste;
+    const int n_apple = FAST ? fm.n_apple : a_n_apple, n_waste = FAST ? fm.n_waste : p.n_waste;
     const bool has_order = !FAST && p.order != nullptr, keep_beams = !FAST && p.keep_beams != 0;
     constexpr bool roll = MODE == kModeRollout;                     // many steps per launch, env resident in LDS
     // A step whose launch also resets the envs that reach the horizon (SSD_AUTO_RESET): the step pass, then -- for those
@@ -1130,7 +1139,7 @@ __global__ void ssd_render_full_kernel(const Params p, int e, uint8_t *rgb) {
     }
 }
 
-template <int GAME, bool F32, int NA, bool STD, bool FAST>
+template <int GAME, bool F32, int NA, bool STD, int FAST>
 static void launch_step(const Params &p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
     if (p.mode == kModeRollout) {
         if constexpr (!F32) hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeRollout, false, NA, STD, FAST>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
@@ -1147,22 +1156,27 @@ static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipS
         // specialised step kernels for the reference's configurations (view 7, beam 5; 5 or 10 agents), and
         // among those the FAST ones for the game's shipped map called in the plain way
         const bool std_view = p.view_len == 7 && p.beam_len == 5;
-        const bool fast = std_view && !p.order && !p.keep_beams &&
-                          (GAME == 0 ? (p.H == 16 && p.W == 38 && p.WP == 45 && p.S == 720 && p.A0 == 336 && p.A1 == 320 && p.n_apple == 155)
-                                     : (p.H == 25 && p.W == 18 && p.WP == 25 && p.S == 640 && p.A0 == 192 && p.A1 == 176 &&
-                                        p.n_apple == 103 && p.n_waste == 119));
+        int fast = 0;
+        for (int f = 1; f <= 2; ++f) {
+            const FastMap &m = kFastMap[GAME][f];
+            if (std_view && !p.order && !p.keep_beams && p.H == m.H && p.W == m.W && p.WP == m.WP && p.S == m.S && p.A0 == m.A0 &&
+                p.A1 == m.A1 && p.n_apple == m.n_apple && (GAME == 0 || p.n_waste == m.n_waste))
+                fast = f;
+        }
         if (std_view && p.N == 5) {
-            if (fast) launch_step<GAME, F32, 5, true, true>(p, grid, block, lds, s);
-            else launch_step<GAME, F32, 5, true, false>(p, grid, block, lds, s);
+            if (fast == 1) launch_step<GAME, F32, 5, true, 1>(p, grid, block, lds, s);
+            else if (GAME == 0 && fast == 2) { if constexpr (GAME == 0) launch_step<GAME, F32, 5, true, 2>(p, grid, block, lds, s); }
+            else launch_step<GAME, F32, 5, true, 0>(p, grid, block, lds, s);
         } else if (std_view && p.N == 10) {
-            if (fast) launch_step<GAME, F32, 10, true, true>(p, grid, block, lds, s);
-            else launch_step<GAME, F32, 10, true, false>(p, grid, block, lds, s);
-        } else if (std_view) launch_step<GAME, F32, 0, true, false>(p, grid, block, lds, s);
-        else launch_step<GAME, F32, 0, false, false>(p, grid, block, lds, s);
+            if (fast == 1) launch_step<GAME, F32, 10, true, 1>(p, grid, block, lds, s);
+            else if (GAME == 1 && fast == 2) { if constexpr (GAME == 1) launch_step<GAME, F32, 10, true, 2>(p, grid, block, lds, s); }
+            else launch_step<GAME, F32, 10, true, 0>(p, grid, block, lds, s);
+        } else if (std_view) launch_step<GAME, F32, 0, true, 0>(p, grid, block, lds, s);
+        else launch_step<GAME, F32, 0, false, 0>(p, grid, block, lds, s);
     } else if (p.mode == kModeReset) {
-        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeReset, F32, 0, false, false>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
+        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeReset, F32, 0, false, 0>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
     } else {
-        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeObserve, F32, 0, false, false>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
+        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeObserve, F32, 0, false, 0>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
     }
 }
 

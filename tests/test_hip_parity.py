@@ -521,15 +521,18 @@ def test_vector_env_in_sync_resets_only_on_the_horizon_step():
     assert venv.engine.steps_since_full_reset is None
 
 
-@pytest.mark.parametrize("cfg", [(K.GAME_HARVEST, 5, 41), (K.GAME_CLEANUP, 10, 24), (K.GAME_HARVEST, 7, 19)])
+@pytest.mark.parametrize("cfg", [(K.GAME_HARVEST, 5, 41), (K.GAME_CLEANUP, 10, 24), (K.GAME_HARVEST, 7, 19),
+                                 (K.GAME_HARVEST, 5, 23, "25x38"), (K.GAME_CLEANUP, 10, 17, "48x36")])
 def test_auto_reset_in_the_step_launch(cfg):
     """SSD_AUTO_RESET: the step launch resets the envs that reach the horizon; same rewards / dones as a plain step, the
     observation rows of finished envs are the reset's, the state afterwards is the reset state (oracle: step, then reset
     with the done flags as the mask).  Envs are put out of phase first; random and explicit actions."""
     import torch
-    game, N, E = cfg
+    game, N, E = cfg[:3]
     Hz = 6
     amap = K.HARVEST_MAP if game == K.GAME_HARVEST else K.CLEANUP_MAP
+    if len(cfg) > 3:                                            # the enlarged maps have kernels of their own (FAST = 2)
+        amap = K.harvest_map_25x38() if cfg[3] == "25x38" else K.cleanup_map_48x36()
     eng = VecEngine(game, amap, num_envs=E, num_agents=N, seed=31)
     ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), seed=31)
     eng.set_horizon(Hz)
