@@ -145,8 +145,13 @@ int ssd_set_state(ssd_env *env, const int8_t *world, const int8_t *beam, const i
  * it runs after the beams and before the spawn).  Host pointer, synchronous. */
 int ssd_get_waste_count(ssd_env *env, uint32_t *waste_count);
 
-/* MapEnv.map_to_colors() on the full grid of env e (map_env.py:316-339): rgb u8 [H,W,3], host pointer. */
+/* MapEnv.map_to_colors() on the full grid of env e (map_env.py:316-339): rgb u8 [H,W,3], host pointer, synchronous. */
 int ssd_render_full(ssd_env *env, int32_t e, uint8_t *rgb);
+
+/* The same for envs [e_begin, e_begin + count) in one go: rgb u8 [count,H,W,3] -- the frames rollout.py:77 and
+ * visuallizer_rllib.py:161 take one env at a time with map_to_colors().  Device pointer (enqueued on `stream`, returns
+ * at once) or, with SSD_HOST_PTRS, host pointer (returns when the frames have arrived).  No other flag applies. */
+int ssd_render_frames(ssd_env *env, int32_t e_begin, int32_t count, uint8_t *rgb, uint32_t flags, void *stream);
 
 /* Episode length.  The reference's agents never report done; episodes end through RLlib's `horizon`
  * (run_scripts/train_baseline.py:131, train_moa.py:122).  horizon > 0: a step whose t reaches it writes

@@ -35,6 +35,7 @@ struct ssd_env {
     uint8_t *st_host = nullptr;      // host view of the mapped block; the st_* pointers above are its device view
     std::vector<void *> host_allocs;
     uint8_t *st_order = nullptr, *st_obs = nullptr, *st_done = nullptr, *st_mask = nullptr, *st_rgb = nullptr;
+    size_t st_rgb_frames = 0;                          // frames st_rgb holds
     // ssd_rollout_random: extra chains (streams + fork / join events), created on first use
     std::vector<hipStream_t> chain_streams;
     std::vector<hipEvent_t> chain_events;
@@ -623,16 +624,48 @@ int ssd_set_state(ssd_env *env, const int8_t *world, const int8_t *beam, const i
     return SSD_OK;
 }
 
+int ssd_render_frames(ssd_env *env, int32_t e_begin, int32_t count, uint8_t *rgb, uint32_t flags, void *stream) {
+    if (!env || !rgb || e_begin < 0 || count < 0 || (int64_t)e_begin + count > env->E) return SSD_E_INVALID;
+    if (flags & ~(uint32_t)SSD_HOST_PTRS) { env->err = "ssd_render_frames: only SSD_HOST_PTRS is meaningful here"; return SSD_E_INVALID; }
+    if (count == 0) return SSD_OK;
+    SSD_HIP(env, hipSetDevice(env->device));
+    const size_t frame = (size_t)env->H * env->W * 3;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint8_t *dst = rgb;
+    if (flags & SSD_HOST_PTRS) {                       // frames are rendered into a device buffer of the handle and copied back
+        if (env->st_rgb_frames < (size_t)count) {
+            void *ptr = nullptr;
+            hipError_t e = hipMalloc(&ptr, (size_t)count * frame);
+            if (e != hipSuccess) { env->err = std::string("hipMalloc: ") + hipGetErrorString(e); return SSD_E_NOMEM; }
+            if (env->st_rgb) {
+                SSD_HIP(env, hipDeviceSynchronize());
+                for (auto &a : env->allocs) if (a == env->st_rgb) a = ptr;
+                SSD_HIP(env, hipFree(env->st_rgb));
+            } else {
+                env->allocs.push_back(ptr);
+            }
+            env->st_rgb = static_cast<uint8_t *>(ptr);
+            env->st_rgb_frames = (size_t)count;
+        }
+        dst = env->st_rgb;
+    }
+    for (int32_t k = 0; k < count; k += 32768) {       // gridDim.y carries the env: at most 65535 per launch
+        const int32_t n = count - k < 32768 ? count - k : 32768;
+        ssd::launch_render_full(env->p, e_begin + k, n, dst + (size_t)k * frame, s);
+    }
+    SSD_HIP(env, hipGetLastError());
+    if (flags & SSD_HOST_PTRS) {
+        SSD_HIP(env, hipMemcpyAsync(rgb, dst, (size_t)count * frame, hipMemcpyDeviceToHost, s));
+        SSD_HIP(env, hipStreamSynchronize(s));
+    }
+    return SSD_OK;
+}
+
 int ssd_render_full(ssd_env *env, int32_t e, uint8_t *rgb) {
     if (!env || !rgb || e < 0 || e >= env->E) return SSD_E_INVALID;
     SSD_HIP(env, hipSetDevice(env->device));
-    const size_t bytes = (size_t)env->H * env->W * 3;
-    if (!env->st_rgb) { int rc = dev_alloc(env, &env->st_rgb, bytes); if (rc) return rc; }
-    SSD_HIP(env, hipDeviceSynchronize());
-    ssd::launch_render_full(env->p, e, env->st_rgb, nullptr);
-    SSD_HIP(env, hipGetLastError());
-    SSD_HIP(env, hipMemcpy(rgb, env->st_rgb, bytes, hipMemcpyDeviceToHost));
-    return SSD_OK;
+    SSD_HIP(env, hipDeviceSynchronize());              // (this entry point takes no stream: order it after everything enqueued)
+    return ssd_render_frames(env, e, 1, rgb, SSD_HOST_PTRS, nullptr);
 }
 
 int ssd_set_horizon(ssd_env *env, int32_t horizon) {

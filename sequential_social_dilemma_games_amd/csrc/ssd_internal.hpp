@@ -75,6 +75,6 @@ struct Params {
 size_t lds_bytes(const Params &p, int envs_per_block, bool f32);
 int envs_per_block(const Params &p, bool f32);
 void launch(const Params &p, int game, void *stream);
-void launch_render_full(const Params &p, int e, uint8_t *rgb_dev, void *stream);
+void launch_render_full(const Params &p, int e0, int count, uint8_t *rgb_dev, void *stream);
 
 }  // namespace ssd

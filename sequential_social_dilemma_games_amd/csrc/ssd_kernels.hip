@@ -1125,9 +1125,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     SSD_STAMP_RT(11);
 }
 
-// MapEnv.map_to_colors() on the whole grid of one env (map_env.py:316-339), one thread per cell.
-__global__ void ssd_render_full_kernel(const Params p, int e, uint8_t *rgb) {
+// MapEnv.map_to_colors() on the whole grids of envs e0 .. e0+gridDim.y-1 (map_env.py:316-339): one thread per cell,
+// blockIdx.y = env; frame k of the launch goes to rgb[k][H][W][3].  Each lane writes its 3 bytes; a wave covers 192
+// contiguous bytes, so the stores coalesce.
+__global__ void ssd_render_full_kernel(const Params p, int e0, uint8_t *rgb) {
     const int hw = p.H * p.W;
+    const int e = e0 + (int)blockIdx.y;
+    uint8_t *out = rgb + (size_t)blockIdx.y * hw * 3;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < hw; c += gridDim.x * blockDim.x) {
         const int g = (c / p.W) * p.WP + c % p.W;                                    // dense cell -> padded-row grid index
         uint32_t ch = p.world[(size_t)e * p.S + g];
@@ -1135,7 +1139,7 @@ __global__ void ssd_render_full_kernel(const Params p, int e, uint8_t *rgb) {
             if ((p.agents[(size_t)e * p.N + i] & 0xFFFFu) == (uint32_t)g) ch = agent_glyph((uint32_t)i);
         if (p.keep_beams) { const uint32_t b = p.beam[(size_t)e * p.S + g]; if (b) ch = b; }   // :299-300
         const uint32_t px = p.lut[ch & 127u];
-        rgb[c * 3 + 0] = (uint8_t)px; rgb[c * 3 + 1] = (uint8_t)(px >> 8); rgb[c * 3 + 2] = (uint8_t)(px >> 16);
+        out[c * 3 + 0] = (uint8_t)px; out[c * 3 + 1] = (uint8_t)(px >> 8); out[c * 3 + 2] = (uint8_t)(px >> 16);
     }
 }
 
@@ -1194,9 +1198,9 @@ void launch(const Params &p_in, int game, void *stream) {
     else { if (f32) launch_game<1, true>(p, grid, block, lds, s); else launch_game<1, false>(p, grid, block, lds, s); }
 }
 
-void launch_render_full(const Params &p, int e, uint8_t *rgb_dev, void *stream) {
+void launch_render_full(const Params &p, int e0, int count, uint8_t *rgb_dev, void *stream) {
     const int hw = p.H * p.W;
-    hipLaunchKernelGGL(ssd_render_full_kernel, dim3((hw + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), p, e, rgb_dev);
+    hipLaunchKernelGGL(ssd_render_full_kernel, dim3((hw + 255) / 256, count), dim3(256), 0, static_cast<hipStream_t>(stream), p, e0, rgb_dev);
 }
 
 }  // namespace ssd

@@ -295,6 +295,30 @@ class VecEngine(object):
         _capi.check(self._L.ssd_render_full(self._h, int(e), _ptr(rgb)), self._h)
         return rgb
 
+    def render_frames(self, e_begin=0, count=None, out=None, host=False):
+        """map_to_colors() of the whole grids of envs [e_begin, e_begin+count) in one launch: u8 [count,H,W,3] -- a device
+        tensor (enqueued on the current stream), or with host=True a NumPy array (synchronous).  These are the frames
+        rollout.py:77 / visuallizer_rllib.py:161 collect one env at a time."""
+        count = self.E - e_begin if count is None else int(count)
+        if e_begin < 0 or count < 0 or e_begin + count > self.E:
+            raise ValueError("env range [%d, %d) outside the batch of %d" % (e_begin, e_begin + count, self.E))
+        shape = (count, self.H, self.W, 3)
+        if host:
+            rgb = np.zeros(shape, np.uint8) if out is None else out
+            if rgb.dtype != np.uint8 or rgb.shape != shape or not rgb.flags.c_contiguous:
+                raise ValueError("out must be a C-contiguous uint8 array of shape %s" % (shape,))
+            if count:
+                _capi.check(self._L.ssd_render_frames(self._h, int(e_begin), count, _ptr(rgb), _capi.SSD_HOST_PTRS, None), self._h)
+            return rgb
+        torch, dev = self._torch()
+        if out is None:
+            out = torch.empty(shape, dtype=torch.uint8, device=dev)
+        elif out.dtype != torch.uint8 or tuple(out.shape) != shape or not out.is_contiguous():
+            raise ValueError("out must be a contiguous uint8 tensor of shape %s" % (shape,))
+        if count:
+            _capi.check(self._L.ssd_render_frames(self._h, int(e_begin), count, self._dp(out), 0, self._stream()), self._h)
+        return out
+
     def status(self, clear=True):
         st = C.c_uint32(0)
         _capi.check(self._L.ssd_device_status(self._h, C.byref(st), int(clear)), self._h)

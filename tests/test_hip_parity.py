@@ -170,6 +170,41 @@ def test_render_full_matches_lut_of_overlay():
         np.testing.assert_array_equal(eng.render_full(e), lut[grid.astype(np.int64)])
 
 
+@pytest.mark.parametrize("game", ["harvest", "cleanup"])
+def test_render_frames_batch_matches_oracle_overlay(game):
+    """ssd_render_frames: every env's full frame in one launch (device tensor and host array), sub-ranges, and the
+    single-frame entry point -- all equal to the colour table applied to the oracle's overlay (map_env.py:280-339)."""
+    import torch
+    gid, amap = (K.GAME_HARVEST, K.HARVEST_MAP) if game == "harvest" else (K.GAME_CLEANUP, K.CLEANUP_MAP)
+    E, N = 37, 5
+    eng = VecEngine(gid, None, num_envs=E, num_agents=N, seed=11, keep_beams=True)
+    ora = pyoracle.Oracle(gid, amap, E, N, G.default_lut(), seed=11)
+    eng.reset_host(); ora.reset()
+    for _ in range(25):
+        eng.step_random_host(); ora.step_random()
+    st = ora.get_state()
+    lut = G.default_lut()
+    want = np.zeros((E, eng.H, eng.W, 3), np.uint8)
+    for e in range(E):
+        grid = st["world"][e].copy()
+        for i in range(N):
+            grid[st["pos"][e, i, 0], st["pos"][e, i, 1]] = ord("12345"[i])
+        grid = np.where(st["beam"][e] != 0, st["beam"][e], grid)
+        want[e] = lut[grid.astype(np.int64)]
+    dev = eng.render_frames()
+    assert dev.is_cuda and tuple(dev.shape) == want.shape
+    np.testing.assert_array_equal(dev.cpu().numpy(), want)
+    np.testing.assert_array_equal(eng.render_frames(host=True), want)
+    np.testing.assert_array_equal(eng.render_frames(5, 9, host=True), want[5:14])
+    out = torch.zeros((3, eng.H, eng.W, 3), dtype=torch.uint8, device=dev.device)
+    assert eng.render_frames(E - 3, 3, out=out) is out
+    np.testing.assert_array_equal(out.cpu().numpy(), want[E - 3:])
+    np.testing.assert_array_equal(eng.render_full(E - 1), want[E - 1])
+    assert eng.render_frames(4, 0, host=True).shape == (0, eng.H, eng.W, 3)
+    with pytest.raises(ValueError):
+        eng.render_frames(30, 8)
+
+
 def test_vector_env_horizon_auto_reset_matches_oracle():
     """SSDVectorEnv: done at t == horizon, masked auto-reset, obs of finished envs = first obs of the next episode."""
     import torch
