@@ -1,5 +1,6 @@
 // tools/microbench/launch_cost.hip -- host cost of hipLaunchKernel by kernel-argument size (empty kernels, one stream).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <chrono>
 #include <cstdio>
 struct A8 { void *p; };
@@ -29,5 +30,16 @@ int main() {
     run("340 B kernarg + 55 KB LDS", [&] { hipLaunchKernelGGL(k340, dim3(256), dim3(128), 55296, s, a340); });
     void *args[] = {&a340};
     run("hipLaunchKernel directly", [&] { hipLaunchKernel((const void *)k340, dim3(256), dim3(128), args, 0, s); });
+    // driver-style launches: function handle looked up once, arguments as an array or as one packed buffer
+    hipFunction_t f = nullptr;
+    if (hipGetFuncBySymbol(&f, (const void *)k340) == hipSuccess && f) {
+        run("hipModuleLaunchKernel (args)", [&] { hipModuleLaunchKernel(f, 256, 1, 1, 128, 1, 1, 0, s, args, nullptr); });
+        size_t sz = sizeof(a340);
+        void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a340, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+        run("hipModuleLaunchKernel (buf)", [&] { hipModuleLaunchKernel(f, 256, 1, 1, 128, 1, 1, 0, s, nullptr, extra); });
+        run("hipExtModuleLaunchKernel (buf)", [&] { hipExtModuleLaunchKernel(f, 256 * 128, 1, 1, 128, 1, 1, 0, s, nullptr, extra, nullptr, nullptr, 0); });
+    } else {
+        printf("hipGetFuncBySymbol unavailable\n");
+    }
     return 0;
 }
