@@ -635,9 +635,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 constexpr int kFire = 7, kClean = 8;
                 uint64_t shooters = SSD_SKIP(2) ? 0ull : ballot(is_agent && (act == kFire || (GAME == 1 && act == kClean)));
                 SSD_NOTE(13, __builtin_popcountll(shooters));
+                SSD_NOTE(15, (GAME == 1 && __builtin_popcountll(shooters) > (STD ? 4 : 64 / (3 * L))) ? 1 : 0);
                 if (is_agent && act == kFire) rew -= 1;                                 // agent.py:170-172 fire_beam('F')
-                const int R = 3 * L, G = STD ? 4 : 64 / R;
-                if (shooters && (GAME == 0 || __builtin_popcountll(shooters) <= G)) {
+                // shooters per pass: 64 / 3L lanes' worth; Cleanup keeps a mask of slots per cell in one byte (below): at most 8
+                const int R = 3 * L, G = STD ? 4 : (GAME == 1 && 64 / R > 8) ? 8 : 64 / R;
+                if (shooters && (GAME == 0 || !has_order || __builtin_popcountll(shooters) <= G)) {
                     // Harvest: a FIRE beam changes nothing another beam reads (no cell types, no blocking cells, harvest.py:62-67;
                     // 'F' marks and penalties commute), so the rays of up to 64 / 3L shooters are traced in ONE pass:
                     // lane = (shooter slot g, ray q, step kk).  A wave with three shooters costs what one shooter costs.
@@ -645,7 +647,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     // would pass through, and 'F' / 'C' marks overwrite each other in action order -- but only where the beams
                     // of two shooters cover the same cell.  So: trace them all at once against the unchanged map, let every
                     // covered cell be claimed by its shooter's slot, and if any lane finds its cell claimed by another slot in
-                    // a way that matters (below) undo the claims and trace the shooters one after the other instead.
+                    // a way that matters (below) let the slots land one after the other instead.  More shooters than slots
+                    // (index action order): group after group, each against the map as the groups before left it.
                     const uint64_t all_shooters = shooters;
                     beams_in_regs = __builtin_popcountll(all_shooters) <= G;            // one pass covers them all
                     const int g = STD ? lane / 15 : lane / R, r = lane - g * R;
@@ -685,29 +688,81 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                         const int ff = f ? __builtin_ctz(f) : L, fs = st ? __builtin_ctz(st) : L;
                         const int len = fs < ff ? fs + 1 : ff;                          // beam covers the stopping cell
                         const bool covered = inray & (kk < len);
+                        bool landed = false;                                            // marks and cleaning already applied
+                        bool top_clean = clean;                                         // kind of the mark that survives on this lane's cell
                         if (GAME == 1 && (all_shooters & (all_shooters - 1))) {         // two or more shooters
-                            // claim = slot, and the beam's kind.  Sharing a cell only matters if the two beams differ in kind
-                            // (which mark survives depends on the order) or both are CLEAN beams stopped by that very 'H'
-                            // (the second one would find it cleaned and go on); 'F' over 'F' and 'C' over 'C' are the same
-                            // either way, and FIRE beams do not see each other.
-                            const uint8_t mine = (uint8_t)((g + 1) | (clean ? 0x10 : 0));
-                            if (covered) s_beam[cidx] = mine;                           // (the beam layer is empty at this point)
-                            wave_sync();
-                            const uint8_t claimed = s_beam[cidx];
-                            if (ballot(covered & (claimed != mine) & ((((claimed ^ mine) & 0x10) != 0) | (clean & (wch == 'H'))))) {
+                            // Which slots cover each cell: one LDS atomic OR per covered lane into the cell's byte of the (still
+                            // empty) beam layer.  Sharing a cell matters in two ways.  (1) Beams of different kind: the mark of
+                            // the later one survives -- with index action order that is the highest slot in the cell's mask, so
+                            // every lane knows the surviving mark without another pass.  (2) Two CLEAN beams on one 'H': the
+                            // second finds it cleaned and goes on -- only then do the slots have to land one after the other.
+                            // 'F' over 'F' and 'C' over 'C' are the same either way, and FIRE beams do not see waste.
+                            const bool one_group = __builtin_popcountll(all_shooters) <= G;
+                            uint32_t others = 0;
+                            if (one_group || !roll) {
+                                if (!one_group) {                                       // the layer holds the earlier groups' marks:
+                                    if (covered) s_beam[cidx] = 0;                      // this group's cells start from an empty byte
+                                    wave_sync();                                        // (they all get this group's marks below)
+                                }
+                                if (covered)
+                                    __hip_atomic_fetch_or(reinterpret_cast<uint32_t *>(s_beam + (cidx & ~3)), (1u << g) << ((cidx & 3) * 8),
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                wave_sync();
+                                const uint32_t m = s_beam[cidx];
+                                others = m & ~(1u << g);
+                                const uint64_t kb = ballot(clean);
+                                uint32_t cs = 0;                                        // slots that hold a CLEAN beam
+                                for (int t = 0; t < G; ++t) cs |= (uint32_t)((kb >> (t * R)) & 1u) << t;
+                                top_clean = ((cs >> (31 - __builtin_clz(m | 1u))) & 1u) != 0;
+                                others = covered ? others : 0u;
+                                const bool two_on_waste = clean & (wch == 'H') & ((others & cs) != 0);
+                                const bool kinds_differ = (others & (clean ? ~cs : cs)) != 0;
+                                landed = ballot(two_on_waste | (has_order & kinds_differ)) != 0;
+                            } else {
+                                landed = true;      // (rollout kernel: later groups land slot by slot -- rare, and the kernel is short of SGPRs)
+                            }
+                            if (landed) SSD_NOTE(15, 2);
+                            if (landed && has_order) {                                  // slots are not in action order:
                                 if (covered) s_beam[cidx] = 0;
                                 wave_sync();
                                 shooters = all_shooters;                                // -> one after the other, below
                                 beams_in_regs = false;
                                 break;
                             }
+                            if (landed) {
+                                // Keep the geometry (cell of every lane, first wall of every ray -- walls do not move) and let
+                                // the slots land in order: a CLEAN slot j re-reads its cells from the map as slots < j left it
+                                // and finds its stops again; every slot marks, CLEAN ones clean.  (Every mask byte is overwritten:
+                                // a ray only ever reaches further than in the first trace.)
+                                const int nsl = taken;                                  // slots in this group
+                                bool cov_fin = covered, did_clean = false;
+                                for (int j = 0; j < nsl; ++j) {
+                                    const bool mej = inray & (g == j);
+                                    const uint8_t w2 = s_world[cidx];
+                                    const uint64_t ms2 = ballot(mej & pass & ((och != 0) | (clean & (w2 == 'H'))));
+                                    const uint32_t st2 = (uint32_t)(ms2 >> sh) & rmask;
+                                    const int fs2 = st2 ? __builtin_ctz(st2) : L;
+                                    const bool cov2 = mej & (kk < (fs2 < ff ? fs2 + 1 : ff));
+                                    if (cov2) {
+                                        s_beam[cidx] = clean ? 'C' : 'F';
+                                        if (clean && w2 == 'H') s_world[cidx] = 'R';
+                                    }
+                                    cov_fin = mej ? cov2 : cov_fin;
+                                    did_clean |= cov2 & clean & (w2 == 'H');
+                                    wave_sync();
+                                }
+                                cleaned += (uint32_t)__builtin_popcountll(ballot(did_clean));
+                                b_cov = cov_fin; b_idx = cidx; b_chr = s_beam[cidx];    // the mark that survived on this lane's cell
+                            }
                         }
-                        b_cov = covered; b_idx = cidx; b_chr = clean ? 'C' : 'F';
-                        if (covered) {
-                            s_beam[cidx] = clean ? 'C' : 'F';                           // :624,:636 firing_points
-                            if (clean && wch == 'H') s_world[cidx] = 'R';               // :625-634 cell_types ['H'] -> ['R']
+                        if (!landed) {
+                            b_cov = covered; b_idx = cidx; b_chr = top_clean ? 'C' : 'F';
+                            if (covered) {
+                                s_beam[cidx] = (uint8_t)b_chr;                          // :624,:636 firing_points
+                                if (clean && wch == 'H') s_world[cidx] = 'R';           // :625-634 cell_types ['H'] -> ['R']
+                            }
+                            if (GAME == 1) cleaned += (uint32_t)__builtin_popcountll(ballot(covered & clean & (wch == 'H')));
                         }
-                        if (GAME == 1) cleaned += (uint32_t)__builtin_popcountll(ballot(covered & clean & (wch == 'H')));
                         // agent.py:166-168 hit('F'): the last-index agent (:603) on a cell where a FIRE ray stopped loses 50 per ray
                         uint64_t hits = ballot(stopper & !clean & (och != 0) & (kk == fs) & (fs < ff));
                         const bool top = __builtin_amdgcn_inverse_ballot_w64(highest);

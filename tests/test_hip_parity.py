@@ -332,6 +332,8 @@ UNUSUAL = [
     (K.GAME_HARVEST, 9, 40, 130, 4, 15, 21, 25),     # widest view (31 x 31) and longest beam
     (K.GAME_CLEANUP, 40, 9, 130, 4, 0, 1, 25),       # 1 x 1 view, beam of one cell
     (K.GAME_CLEANUP, 20, 20, 64, 7, 7, 5, 60),
+    (K.GAME_CLEANUP, 24, 8, 49, 12, 8, 1, 40),       # beam of one cell, 12 agents: more shooters than the 8 slots a cell's mask holds
+    (K.GAME_CLEANUP, 14, 14, 40, 16, 3, 2, 40),      # 10 shooters' worth of lanes, 16 agents: several groups of 8
 ]
 
 

@@ -74,10 +74,20 @@ def main():
             print("    %-24s %5.1f %% of envs: mean %.2f us, max %.2f us, mean %.0f cycles" % (
                 name, 100.0 * float(m.double().mean()), float(dur[m].mean()), float(dur[m].max()), float(cyc[m].mean())))
     d_last = s[:, 1:10] - s[:, 0:9]
+    for code, name in ((0, "beams: one parallel pass"), (1, "beams: more shooters than slots"), (2, "beams: conflict -> one by one")):
+        m = (s[:, 15] == code) & (shots >= 1)
+        if m.any():
+            print("    %-32s %5.2f %% of envs: beams phase mean %.0f cycles, wave mean %.2f us, max %.2f us" % (
+                name, 100.0 * float(m.double().mean()), float(d_last[m][:, 3].mean()), float(dur[m].mean()), float(dur[m].max())))
     idx = dur.sort().indices
     for name, sel in (("fastest 10 %", idx[: E // 10]), ("middle 10 %", idx[E // 2 - E // 20: E // 2 + E // 20]), ("slowest 1 %", idx[-max(E // 100, 1):])):
         print("    %-13s phases (cycles): " % name + " ".join("%s %.0f" % (n.split()[0], v) for n, v in zip(NAMES, d_last[sel].mean(dim=0).tolist()) if n != "wg barrier")
               + " | starts %.2f us" % float(starts[sel].mean()))
+    if os.environ.get("SSD_SHOW_SLOWEST"):
+        for w in idx[-int(os.environ["SSD_SHOW_SLOWEST"]):].tolist():
+            print("      env %5d: %.2f us (start %.2f) slow-move %d shooters %d beams-code %d | " % (
+                w, float(dur[w]), float(starts[w]), int(s[w, 12]), int(s[w, 13]), int(s[w, 15]))
+                + " ".join("%s %d" % (n.split()[0], v) for n, v in zip(NAMES, d_last[w].tolist()) if n != "wg barrier"))
     if chains:
         for c in range(chains):
             lo, hi = E * c // chains, E * (c + 1) // chains
