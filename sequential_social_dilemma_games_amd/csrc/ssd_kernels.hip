@@ -498,6 +498,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     // ascending cell order (scalar min over the few lanes involved).  The shuffle of :421-423 only
                     // decides who wins such a cell, so it is only computed when there is one (draws are counter-keyed).
                     uint64_t todo = dupm & M;
+                    SSD_NOTE(12, todo ? 2 : 1);
                     if (todo) {
                         const int nm = __builtin_popcountll(M);
                         uint32_t perm = 0;                       // lane k: k-th entry of the (shuffled) zipped list
@@ -509,8 +510,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                             }
                         }
                         const uint32_t pk = phase_key(key, t, kMove);
+                        // draw i is keyed by i alone: lane i computes its own, all at once; only the swaps are sequential
+                        const uint32_t jv = randint(draw(pk, (uint32_t)lane), (uint32_t)lane + 1);
                         for (int i = nm - 1; i >= 1; --i) {      // :421-423 np.random.shuffle = Fisher-Yates from the end
-                            const uint32_t j = randint(draw(pk, (uint32_t)i), (uint32_t)i + 1);
+                            const uint32_t j = rl(jv, i);
                             const uint32_t vi = rl(perm, i), vj = rl(perm, j);
                             if (lane == i) perm = vj;
                             if (lane == (int)j) perm = vi;
@@ -554,17 +557,22 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                         // longer cycles rotate (:540-543).  Resolved by pointer jumping over lanes, ceil(log2 N) rounds.
                         const bool pend = __builtin_amdgcn_inverse_ballot_w64(Hm) & (mvcell != cell);
                         int st = pend ? (occ_of_target < 0 ? 1 : 2) : 0;                // 0 stays, 1 moves, 2 waits for lane `nx`
-                        const int nx0 = (occ_of_target & 63) << 2;
-                        int nx = nx0;
-                        for (int r = 1; r < N; r <<= 1) {
-                            const int s2 = __builtin_amdgcn_ds_bpermute(nx, st), n2 = __builtin_amdgcn_ds_bpermute(nx, nx);
-                            const bool waiting = st == 2;
-                            st = (waiting & (s2 != 2)) ? s2 : st;
-                            nx = (waiting & (s2 == 2)) ? n2 : nx;
-                        }
-                        if (ballot(st == 2)) {                                          // still waiting: on a cycle
-                            const int back = __builtin_amdgcn_ds_bpermute(nx0, nx0);    // my target's target ...
-                            st = st == 2 ? (back == (lane << 2) ? 0 : 1) : st;          // ... is me: a swap
+                        // Most often nobody waits for an agent that is itself about to move (the agent in the way is firing,
+                        // turning, blocked by a wall or staying): then free targets are taken and the rest stay, no jumping.
+                        const uint64_t pendm = ballot(pend);
+                        if (ballot((st == 2) & (((pendm >> (occ_of_target & 63)) & 1ull) != 0))) {
+                            const int nx0 = (occ_of_target & 63) << 2;
+                            int nx = nx0;
+                            for (int r = 1; r < N; r <<= 1) {
+                                const int s2 = __builtin_amdgcn_ds_bpermute(nx, st), n2 = __builtin_amdgcn_ds_bpermute(nx, nx);
+                                const bool waiting = st == 2;
+                                st = (waiting & (s2 != 2)) ? s2 : st;
+                                nx = (waiting & (s2 == 2)) ? n2 : nx;
+                            }
+                            if (ballot(st == 2)) {                                      // still waiting: on a cycle
+                                const int back = __builtin_amdgcn_ds_bpermute(nx0, nx0);    // my target's target ...
+                                st = st == 2 ? (back == (lane << 2) ? 0 : 1) : st;      // ... is me: a swap
+                            }
                         }
                         if (st == 1) cell = mvcell;
                     } else

@@ -74,6 +74,11 @@ def main():
             print("    %-24s %5.1f %% of envs: mean %.2f us, max %.2f us, mean %.0f cycles" % (
                 name, 100.0 * float(m.double().mean()), float(dur[m].mean()), float(dur[m].max()), float(cyc[m].mean())))
     d_last = s[:, 1:10] - s[:, 0:9]
+    for code, name in ((0, "move: fast path"), (1, "move: slow path, no contested cell"), (2, "move: slow path, contested cell (shuffle)")):
+        m = s[:, 12] == code
+        if m.any():
+            print("    %-42s %5.2f %% of envs: move phase mean %.0f cycles, max %.0f" % (
+                name, 100.0 * float(m.double().mean()), float(d_last[m][:, 1].mean()), float(d_last[m][:, 1].max())))
     for code, name in ((0, "beams: one parallel pass"), (1, "beams: more shooters than slots"), (2, "beams: conflict -> one by one")):
         m = (s[:, 15] == code) & (shots >= 1)
         if m.any():
