@@ -12,7 +12,7 @@ for E in (64, 4096):
     eng = VecEngine(K.GAME_HARVEST, None, num_envs=E, num_agents=5, seed=0)
     out = eng.alloc_outputs()
     ring = tuple(t.unsqueeze(0) for t in out)
-    for chains in (1, 2, 4):
+    for chains in (1, 2, 3, 4):
         eng.set_rollout_chains(chains)
         eng.rollout_random(300, *ring)
         torch.cuda.synchronize()
