@@ -423,6 +423,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             int act = -1;
             uint32_t ordv = (uint32_t)lane;                      // action order list, lane k = k-th acting agent
             int nord = N;
+            bool all_apart = false;                              // known: no two agents share a cell after the moves
             if (is_step) {
                 t += 1;
                 // ---- actions (map_env.py:171-173) ----
@@ -491,6 +492,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 SSD_NOTE(12, slow ? 1 : 0);
                 if (!slow) {
                     if (mover) cell = tcell;
+                    all_apart = (clashm & agents_m) == 0;        // nobody's target is anybody else's target or cell
                 } else {                                         // :415 (M != 0 here)
                     __builtin_amdgcn_s_setprio(3);               // the slowest waves of a launch come through here (1-2 % of the envs)
                     uint64_t Hm = M;                             // ids that still have an entry in agent_moves
@@ -624,6 +626,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 // bit is set among the agents standing where it stands.
                 const uint64_t agents = N >= 64 ? ~0ull : bit((uint32_t)N) - 1;
                 uint64_t lowest = 0;
+                if (all_apart) {                                 // (the move phase already compared every pair of cells)
+                    lowest = highest = agents;
+                } else
                 for (int j = 0; j < N; ++j) {
                     const uint64_t here = ballot(cell == rl(cell, j)) & agents;
                     lowest |= (here & (bit(j) - 1)) ? 0ull : bit(j);
