@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--gather", action="store_true", help="RCCL all-gather of obs/rew after every step")
     ap.add_argument("--obs-f32", action="store_true", help="separate mode: the kernel writes float32 observations (4x the obs bytes)")
     ap.add_argument("--per-step-calls", action="store_true", help="one Python call per step instead of ssd_rollout_random")
+    ap.add_argument("--pipelined", action="store_true", help="ask ssd_rollout_random for SSD_ROLLOUT_PIPELINED (needs --ring >= 2)")
+    ap.add_argument("--ring", type=int, default=1, help="output ring slots of ssd_rollout_random (step k writes slot k %% ring)")
     ap.add_argument("--chains", type=int, default=0, help="env ranges stepped concurrently by ssd_rollout_random (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -147,11 +149,12 @@ def main():
     # Without --gather / --per-step-calls the steps are enqueued by ssd_rollout_random: the same launches (one step
     # kernel per step into the same output buffers, a full reset every HORIZON steps), issued by one library call per
     # chunk instead of one Python call per step, so that the host never starves the 9 us kernels.
-    ring = tuple(t.unsqueeze(0) for t in out)
+    ring = tuple(t.unsqueeze(0) for t in out) if args.ring <= 1 else \
+        tuple(torch.empty((args.ring,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in out)
     use_rollout = not args.per_step_calls
     chains = 1
     if use_rollout:                                # env ranges the library steps on streams of its own (envs are independent)
-        chains = args.chains if args.chains > 0 else (2 if E >= 2048 else 1)
+        chains = args.chains if args.chains > 0 else (1 if args.pipelined else 2 if E >= 2048 else 1)   # (a pipelined chain overlaps its own launches)
         eng.set_rollout_chains(chains)
 
     def run_steps(k0, n):
@@ -180,7 +183,8 @@ def main():
             main.wait_stream(comm_stream)              # the K steps are not done before their last collective is
         elif use_rollout:
             for c0 in range(k0, k0 + n, 1000):
-                eng.rollout_random(min(1000, k0 + n - c0), ring[0], ring[1], ring[2], reset_every=HORIZON, step0=c0)
+                eng.rollout_random(min(1000, k0 + n - c0), ring[0], ring[1], ring[2], reset_every=HORIZON, step0=c0,
+                                   pipelined=args.pipelined)
         else:
             for k in range(k0, k0 + n):
                 one_step(k)

@@ -59,6 +59,14 @@ enum {
                                 are 1) starts its next episode in the same launch: MapEnv.reset (map_env.py:214-249) is applied to it
                                 and its observation rows are the reset's (unrotated, :239-240), as if ssd_reset had been called with
                                 the done flags as the mask.  uint8 obs only. */
+    SSD_ROLLOUT_PIPELINED = 1u << 5, /* ssd_rollout_random only, a request: the step launches of a chain alternate between two streams
+                                and every env's wave waits for that env's previous step (a per-env counter in device memory) instead
+                                of the whole previous launch -- step k+1 starts env by env while step k's slower envs are still at
+                                work.  Same launches, same results.  Honoured when a map-specific uint8 kernel runs (the shipped
+                                and the enlarged maps), ring >= 2 (consecutive steps must not share an output slot) and two launches' waves fit on
+                                the device with a fifth of it to spare (up to ~3200 envs of the shipped maps on MI355X); ignored otherwise.  It pays while the
+                                device has room to spare: 2048 envs 5.8 -> 4.8 us per step, no gain at 4096.  A wave that waits in
+                                vain (tens of ms: the device is oversubscribed by other work) sets SSD_ST_PIPE_TIMEOUT. */
     SSD_OBS_F32 = 1u << 2    /* obs points at float32 [E,N,V,V,3] instead of uint8: the normalisation of map_env.py:199
                                 fused into the kernel (4x the observation bytes; a separate, slower mode) */
 };
@@ -67,7 +75,8 @@ enum {
 enum {
     SSD_ST_BAD_ACTION = 1u << 0,  /* action id outside the game's Discrete(n): KeyError in agent.action_map */
     SSD_ST_NO_SPAWN = 1u << 1,    /* not enough spawn points (assert at map_env.py:661) */
-    SSD_ST_MOVE_LOOKUP = 1u << 2  /* agent_by_pos lookup miss (would be a KeyError at map_env.py:506) */
+    SSD_ST_MOVE_LOOKUP = 1u << 2, /* agent_by_pos lookup miss (would be a KeyError at map_env.py:506) */
+    SSD_ST_PIPE_TIMEOUT = 1u << 3 /* SSD_ROLLOUT_PIPELINED: a wave gave up waiting for its env's previous step; results are invalid */
 };
 
 typedef struct ssd_env ssd_env;

@@ -40,6 +40,11 @@ struct ssd_env {
     std::vector<hipStream_t> chain_streams;
     std::vector<hipEvent_t> chain_events;
     hipEvent_t fork_event = nullptr;
+    // pipelined rollouts: per-env pass counters, and per chain a second stream (launches alternate) with its events
+    uint32_t *pipe_flags = nullptr;
+    struct ChainPipe { hipStream_t sb = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr; };
+    ChainPipe chain_pipe[8];
+    int wave_slots = 0;               // resident waves the device can hold (CUs x 32)
     int rollout_chains = 0;           // 0 = automatic
     std::string err;
 };
@@ -385,6 +390,11 @@ int ssd_destroy(ssd_env *env) {
     for (hipStream_t cs : env->chain_streams) (void)hipStreamDestroy(cs);
     for (hipEvent_t ce : env->chain_events) (void)hipEventDestroy(ce);
     if (env->fork_event) (void)hipEventDestroy(env->fork_event);
+    for (auto &cp : env->chain_pipe) {
+        if (cp.sb) (void)hipStreamDestroy(cp.sb);
+        if (cp.ev_a) (void)hipEventDestroy(cp.ev_a);
+        if (cp.ev_b) (void)hipEventDestroy(cp.ev_b);
+    }
     delete env;
     return SSD_OK;
 }
@@ -414,7 +424,23 @@ int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, voi
 }
 
 // One chain of a rollout: the launches of steps [0, n_steps) for envs [e_begin, e_end), enqueued on `s`.
-static int rollout_chain(ssd_env *env, int e_begin, int e_end, int32_t num_actions, int32_t n_steps, int32_t reset_every,
+// (main thread, before the chains' threads start) what chain c needs to pipeline its launches
+static int ensure_chain_pipe(ssd_env *env, int c) {
+    if (!env->pipe_flags) { int rc = dev_alloc(env, &env->pipe_flags, (size_t)env->E); if (rc) return rc; }
+    if (!env->wave_slots) {
+        int cus = 0;
+        SSD_HIP(env, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, env->device));
+        env->wave_slots = cus * 32;
+    }
+    auto &cp = env->chain_pipe[c];
+    if (cp.sb) return SSD_OK;
+    SSD_HIP(env, hipStreamCreateWithFlags(&cp.sb, hipStreamNonBlocking));
+    SSD_HIP(env, hipEventCreateWithFlags(&cp.ev_a, hipEventDisableTiming));
+    SSD_HIP(env, hipEventCreateWithFlags(&cp.ev_b, hipEventDisableTiming));
+    return SSD_OK;
+}
+
+static int rollout_chain(ssd_env *env, int chain, bool pipelined, int e_begin, int e_end, int32_t num_actions, int32_t n_steps, int32_t reset_every,
                          int32_t step0, uint8_t *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, hipStream_t s) {
     if (hipSetDevice(env->device) != hipSuccess) return SSD_E_DEVICE;
     const bool f32 = (flags & SSD_OBS_F32) != 0;
@@ -429,6 +455,38 @@ static int rollout_chain(ssd_env *env, int e_begin, int e_end, int32_t num_actio
         p.n_steps = n_steps; p.reset_every = reset_every; p.step0 = step0; p.ring = ring;
         p.obs = obs; p.rew = rew; p.done = done;
         ssd::launch(p, env->game, s);
+        return hipGetLastError() == hipSuccess ? SSD_OK : SSD_E_DEVICE;
+    }
+    if (pipelined) {
+        // Step launches alternate between the chain's stream and a second one, so two consecutive steps may be in flight at
+        // once; what orders them is the per-env pass counter the kernels wait on and publish (kernel: PIPE).  A reset launch
+        // joins the two streams, runs alone, and the counters start again from zero.
+        auto &cp = env->chain_pipe[chain];
+        hipStream_t st[2] = {s, cp.sb};
+        uint32_t seq = 0;
+        auto restart = [&]() -> bool {
+            seq = 0;
+            return hipMemsetAsync(env->pipe_flags + e_begin, 0, sizeof(uint32_t) * (size_t)(e_end - e_begin), s) == hipSuccess &&
+                   hipEventRecord(cp.ev_a, s) == hipSuccess && hipStreamWaitEvent(cp.sb, cp.ev_a, 0) == hipSuccess;
+        };
+        auto join = [&]() -> bool { return hipEventRecord(cp.ev_b, cp.sb) == hipSuccess && hipStreamWaitEvent(s, cp.ev_b, 0) == hipSuccess; };
+        if (!restart()) return SSD_E_DEVICE;
+        for (int k = 0; k < n_steps; ++k) {
+            const size_t slot = (size_t)((step0 + k) % ring);
+            p.obs = obs ? obs + slot * ob : nullptr;
+            if (reset_every > 0 && (step0 + k) % reset_every == 0) {
+                if (!join()) return SSD_E_DEVICE;
+                p.mode = ssd::kModeReset; p.rotate = 0; p.num_actions_random = 0; p.rew = nullptr; p.done = nullptr;
+                p.pipe_flags = nullptr;
+                ssd::launch(p, env->game, s);
+                if (!restart()) return SSD_E_DEVICE;
+            }
+            p.mode = ssd::kModeStep; p.rotate = 1; p.num_actions_random = num_actions;
+            p.rew = rew ? rew + slot * en : nullptr; p.done = done ? done + slot * en : nullptr;
+            p.pipe_flags = env->pipe_flags; p.pipe_seq = ++seq;
+            ssd::launch(p, env->game, st[(seq - 1) & 1]);
+        }
+        if (!join()) return SSD_E_DEVICE;
         return hipGetLastError() == hipSuccess ? SSD_OK : SSD_E_DEVICE;
     }
     for (int k = 0; k < n_steps; ++k) {
@@ -459,13 +517,36 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
     // Envs are independent, so a rollout is as many independent launch chains as we like.  Two chains on two streams
     // (each enqueued by its own host thread) keep the GPU busy while the other chain's kernel drains and the next one is
     // dispatched -- the ~2 us per launch that a single chain of 9 us kernels cannot hide.  SSD_ROLLOUT_CHAINS overrides.
+    // Pipelined launches (SSD_ROLLOUT_PIPELINED; SSD_ROLLOUT_PIPELINE=1 / 0 in the environment forces / forbids them): only the
+    // known maps' uint8 kernels have the variant, consecutive steps must not share an output slot, and the launches that can
+    // be in flight together must fit on the device with room to spare -- a wave that waits for its env's previous pass must
+    // never keep that pass from getting a slot.
+    static const int env_pipe = [] { const char *v = getenv("SSD_ROLLOUT_PIPELINE"); return v ? (atoi(v) != 0 ? 1 : 0) : -1; }();
+    bool pipelined = (env_pipe >= 0 ? env_pipe == 1 : (flags & SSD_ROLLOUT_PIPELINED) != 0) &&
+                     !(flags & (SSD_ROLLOUT_FUSED | SSD_OBS_F32)) && ring >= 2 && n_steps >= 2 &&
+                     ssd::fast_profile(env->p, env->game) > 0;
+    if (pipelined) {
+        int rc = ensure_chain_pipe(env, 0);
+        if (rc) return rc;
+        // resident waves the device can hold of this kernel: 32 per CU, or what 160 KB of LDS per CU allow.  Two launches of a
+        // chain can be in flight at once: they must fit with a fifth of the device to spare (other streams' kernels).
+        Params q = env->p;
+        q.mode = ssd::kModeStep;
+        const size_t lds_wave = ssd::lds_bytes(q, 1, false);
+        const int per_cu = (int)((size_t)160 * 1024 / (lds_wave ? lds_wave : 1));
+        const long long cap = (long long)(env->wave_slots / 32) * (per_cu < 32 ? per_cu : 32);
+        static const bool tight = [] { const char *v = getenv("SSD_PIPELINE_TIGHT"); return v && atoi(v) != 0; }();   // tuning: no margin
+        if (2LL * env->E * (tight ? 4 : 5) > cap * 4) pipelined = false;
+    }
     static const int forced = [] { const char *v = getenv("SSD_ROLLOUT_CHAINS"); return v ? atoi(v) : 0; }();
     int chains = env->rollout_chains > 0 ? env->rollout_chains : forced > 0 ? forced : (env->E >= 2048 && n_steps >= 16 ? 2 : 1);
     if ((flags & SSD_ROLLOUT_FUSED) && env->rollout_chains <= 0 && forced <= 0) chains = 1;   // one launch already covers the whole rollout
+    if (pipelined && env->rollout_chains <= 0 && forced <= 0) chains = 1;   // a pipelined chain overlaps its own launches (measured: 1 beats 2)
     if (chains > 8) chains = 8;
     if (chains > env->E) chains = env->E;
+    for (int c = 1; pipelined && c < chains; ++c) { int rc = ensure_chain_pipe(env, c); if (rc) return rc; }
     if (chains <= 1) {
-        int rc = rollout_chain(env, 0, env->E, num_actions, n_steps, reset_every, step0, o, rew, done, ring, flags, s);
+        int rc = rollout_chain(env, 0, pipelined, 0, env->E, num_actions, n_steps, reset_every, step0, o, rew, done, ring, flags, s);
         if (rc) env->err = "kernel launch failed in ssd_rollout_random";
         return rc;
     }
@@ -484,10 +565,10 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
     auto range = [&](int c) { return (int)(((long long)env->E * c) / chains); };
     for (int c = 1; c < chains; ++c)
         workers.emplace_back([&, c] {
-            rcs[c] = rollout_chain(env, range(c), range(c + 1), num_actions, n_steps, reset_every, step0, o, rew, done, ring, flags,
+            rcs[c] = rollout_chain(env, c, pipelined, range(c), range(c + 1), num_actions, n_steps, reset_every, step0, o, rew, done, ring, flags,
                                    env->chain_streams[c - 1]);
         });
-    rcs[0] = rollout_chain(env, range(0), range(1), num_actions, n_steps, reset_every, step0, o, rew, done, ring, flags, s);
+    rcs[0] = rollout_chain(env, 0, pipelined, range(0), range(1), num_actions, n_steps, reset_every, step0, o, rew, done, ring, flags, s);
     for (auto &w : workers) w.join();
     // join: the caller's stream continues after every chain
     for (int c = 1; c < chains; ++c) {

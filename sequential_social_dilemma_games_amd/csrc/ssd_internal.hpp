@@ -70,10 +70,15 @@ struct Params {
     uint8_t *done;                 // [E][N]
     uint32_t dbg_skip;             // diagnostic builds (-DSSD_STAMPS) only: bit mask of phases to skip (tools/variant_times.py)
     unsigned long long *stamps;    // [E][16] s_memtime stamps; diagnostic builds (-DSSD_STAMPS) only, else null
+    // pipelined rollouts: [E] number of the last pass each env has completed in this rollout call, and this launch's number.
+    // A launch with pipe_flags waits, env by env, for pass pipe_seq - 1 instead of relying on stream order (see ssd_capi.hip).
+    uint32_t *pipe_flags;
+    uint32_t pipe_seq;
 };
 
 size_t lds_bytes(const Params &p, int envs_per_block, bool f32);
 int envs_per_block(const Params &p, bool f32);
+int fast_profile(const Params &p, int game);    // which map-specific step kernel a launch gets (0: the general ones)
 void launch(const Params &p, int game, void *stream);
 void launch_render_full(const Params &p, int e0, int count, uint8_t *rgb_dev, void *stream);
 

@@ -38,6 +38,7 @@ namespace ssd {
 constexpr uint32_t kStBadAction = 1u << 0;
 constexpr uint32_t kStNoSpawn = 1u << 1;
 constexpr uint32_t kStMoveLookup = 1u << 2;
+constexpr uint32_t kStPipeTimeout = 1u << 3;    // a pipelined launch gave up waiting for an env's previous pass
 
 // ---------------------------------------------------------------------------------------------
 // shared PRNG (prng.py): triple32 chain
@@ -217,7 +218,12 @@ constexpr FastMap kFastMap[2][3] = {
     {{0, 0, 0, 0, 0, 0, 0, 0}, {16, 38, 45, 720, 336, 320, 155, 0}, {25, 38, 45, 1136, 336, 320, 252, 0}},
     {{0, 0, 0, 0, 0, 0, 0, 0}, {25, 18, 25, 640, 192, 176, 103, 119}, {48, 36, 43, 2064, 320, 304, 412, 476}}};
 
-template <int GAME, int MODE, bool F32, int NA, bool STD, int FAST>
+// PIPE: a launch of a pipelined rollout (ssd_rollout_random, step launches alternating between two streams): instead of
+// stream order, every env's wave waits until that env's previous pass has published its state (flag = pass number, agent-
+// scope release / acquire), and publishes its own right after the write-back -- before it renders the observations.  Waves
+// of step k+1 thus start env by env while step k's slower waves are still at work, and the ~1.5 us between dependent
+// launches disappears from the critical path.  The wait is bounded: a wave that gives up sets kStPipeTimeout.
+template <int GAME, int MODE, bool F32, int NA, bool STD, int FAST, bool PIPE = false>
 // The leading arguments repeat the Params fields the first global loads need (14 dwords).  Built with
 // -mllvm -amdgpu-kernarg-preload-count=14 the command processor delivers them in SGPRs when the wave starts, so the
 // loads of the env's state go out without first waiting ~0.3 us for a scalar load of the kernel arguments.
@@ -270,21 +276,49 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     SSD_NOTE(14, t_entry);
     SSD_STAMP(0);
 
+    bool pipe_timeout = false;
+    if constexpr (PIPE) {
+        if (active) {
+            const uint32_t want = p.pipe_seq - 1u;
+            uint32_t spins = 0;
+            while (__hip_atomic_load(p.pipe_flags + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > 40000u) { pipe_timeout = true; break; }     // (tens of milliseconds: never in a healthy run)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // (compiler ordering; the state loads below are coherent ones)
+        }
+    }
     if (active) {
         const bool is_agent = lane < N;
         // ---- prologue: every global load of the env is issued before the first use, so the HBM / L2
         //      latency is paid once.  First the loads whose addresses come from the preloaded arguments alone (hdr, agents,
         //      the first 1 KiB of the grid = the whole grid of the shipped maps, the colour table, the apple list), then
         //      the ones that need further kernel arguments (actions, order, waste list).
-        const uint4 hdr = a_hdr[e];
+        // (PIPE: the env's state may have been written a moment ago by a wave on another XCD, i.e. behind another L2: agent-
+        // scope loads and stores, dword by dword, instead of cache write-backs / invalidations around ordinary ones)
+        auto cload = [](const uint32_t *ptr) -> uint32_t {
+            return PIPE ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ptr;
+        };
+        uint4 hdr;
+        if (PIPE) {
+            const uint32_t hv = cload(reinterpret_cast<const uint32_t *>(a_hdr + e) + (lane & 3));
+            hdr = make_uint4(rl(hv, 0), rl(hv, 1), rl(hv, 2), rl(hv, 3));
+        } else {
+            hdr = a_hdr[e];
+        }
         uint32_t areg = 0;
         int act_in = -1;
         uint32_t ord_in = 0xFFu;
-        if (mode != kModeReset && is_agent) areg = a_agents[(size_t)e * N + lane];
+        if (mode != kModeReset && is_agent) areg = cload(a_agents + (size_t)e * N + lane);
         const uint8_t *gsrc = mode == kModeReset ? p.reset_world : a_world + (size_t)e * S;
         uint4 w0 = make_uint4(0, 0, 0, 0), b0 = make_uint4(0, 0, 0, 0);
         if (lane * 16 < S) {
-            w0 = *reinterpret_cast<const uint4 *>(gsrc + lane * 16);
+            if (PIPE) {
+                const uint32_t *g4 = reinterpret_cast<const uint32_t *>(gsrc + lane * 16);
+                w0 = make_uint4(cload(g4), cload(g4 + 1), cload(g4 + 2), cload(g4 + 3));
+            } else {
+                w0 = *reinterpret_cast<const uint4 *>(gsrc + lane * 16);
+            }
             if (mode == kModeObserve && keep_beams) b0 = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + lane * 16);
         }
         // glyph -> RGB table of the observation phase, one copy per wave
@@ -320,7 +354,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         uint32_t key = rfl(hdr.x), t = rfl(hdr.y), episode = rfl(hdr.z);
         s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b;
         if (obs_f32) reinterpret_cast<float4 *>(s_f32)[lane] = flut;
-        uint32_t status = 0;
+        uint32_t status = pipe_timeout ? kStPipeTimeout : 0u;
         uint32_t cell = areg & 0xFFFFu, orient = mode == kModeReset ? 2u : (areg >> 16) & 3u;   // lane = agent index
         int rew = 0;
         // grid -> LDS (16 B per lane); beam and occupancy layers start empty
@@ -338,7 +372,12 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         for (int i = lane * 16 + 1024; i < S; i += 1024) {   // maps above 1024 cells
             uint4 bv = make_uint4(0, 0, 0, 0);
             if (mode == kModeObserve && keep_beams) bv = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + i);
-            *reinterpret_cast<uint4 *>(s_world + i) = *reinterpret_cast<const uint4 *>(gsrc + i);
+            if (PIPE) {
+                const uint32_t *g4 = reinterpret_cast<const uint32_t *>(gsrc + i);
+                *reinterpret_cast<uint4 *>(s_world + i) = make_uint4(cload(g4), cload(g4 + 1), cload(g4 + 2), cload(g4 + 3));
+            } else {
+                *reinterpret_cast<uint4 *>(s_world + i) = *reinterpret_cast<const uint4 *>(gsrc + i);
+            }
             *reinterpret_cast<uint4 *>(s_beam + i) = bv;
             *reinterpret_cast<uint4 *>(s_occ + i) = make_uint4(0, 0, 0, 0);
         }
@@ -353,6 +392,24 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         uint32_t waste_cur = GAME == 1 ? rfl(hdr.w) >> 16 : 0u;
         auto write_state = [&]() {
             uint8_t *gw = a_world + (size_t)e * S;
+            if constexpr (PIPE) {
+                auto cstore = [](uint32_t *ptr, uint32_t v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+                for (int i = lane * 16; i < S; i += 64 * 16) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(s_world + i);
+                    uint32_t *g4 = reinterpret_cast<uint32_t *>(gw + i);
+                    cstore(g4, v.x); cstore(g4 + 1, v.y); cstore(g4 + 2, v.z); cstore(g4 + 3, v.w);
+                }
+                if (is_agent) cstore(a_agents + (size_t)e * N + lane, cell | (orient << 16));
+                if (lane < 4) cstore(reinterpret_cast<uint32_t *>(a_hdr + e) + lane,
+                                     lane == 0 ? key : lane == 1 ? t : lane == 2 ? episode : (waste_last | (waste_cur << 16)));
+                if (status && lane == 0) atomicOr(p.status, status);
+                // publish: once these stores have completed (they are write-through at agent scope, so no L2 write-back is
+                // needed -- but a workgroup-scope fence alone emits no wait for them) this env's next pass may start
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) cstore(p.pipe_flags + e, p.pipe_seq);
+                return;
+            }
             for (int i = lane * 16; i < S; i += 64 * 16) {
                 *reinterpret_cast<uint4 *>(gw + i) = *reinterpret_cast<const uint4 *>(s_world + i);
                 if (keep_beams)
@@ -1218,8 +1275,30 @@ static void launch_step(const Params &p, dim3 grid, dim3 block, size_t lds, hipS
     } else if (p.mode == kModeStepAuto) {
         if constexpr (!F32) hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStepAuto, false, NA, STD, FAST>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
     } else {
+        if constexpr (!F32 && FAST != 0) {           // (the kernels rollouts of the known maps use)
+            if (p.pipe_flags) {
+                hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStep, false, NA, STD, FAST, true>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
+                return;
+            }
+        }
         hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStep, F32, NA, STD, FAST>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
     }
+}
+
+// Which FAST kernel (0 = none) a step launch with these parameters gets: the map and call form must match kFastMap, and the
+// (game, agents, profile) combination must be one that is instantiated below.
+int fast_profile(const Params &p, int game) {
+    const bool std_view = p.view_len == 7 && p.beam_len == 5;
+    int fast = 0;
+    for (int f = 1; f <= 2; ++f) {
+        const FastMap &m = kFastMap[game][f];
+        if (std_view && !p.order && !p.keep_beams && p.H == m.H && p.W == m.W && p.WP == m.WP && p.S == m.S && p.A0 == m.A0 &&
+            p.A1 == m.A1 && p.n_apple == m.n_apple && (game == 0 || p.n_waste == m.n_waste))
+            fast = f;
+    }
+    if (p.N != 5 && p.N != 10) fast = 0;
+    if (fast == 2 && ((p.N == 5 && game != 0) || (p.N == 10 && game != 1))) fast = 0;
+    return fast;
 }
 
 template <int GAME, bool F32>
@@ -1228,13 +1307,7 @@ static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipS
         // specialised step kernels for the reference's configurations (view 7, beam 5; 5 or 10 agents), and
         // among those the FAST ones for the game's shipped map called in the plain way
         const bool std_view = p.view_len == 7 && p.beam_len == 5;
-        int fast = 0;
-        for (int f = 1; f <= 2; ++f) {
-            const FastMap &m = kFastMap[GAME][f];
-            if (std_view && !p.order && !p.keep_beams && p.H == m.H && p.W == m.W && p.WP == m.WP && p.S == m.S && p.A0 == m.A0 &&
-                p.A1 == m.A1 && p.n_apple == m.n_apple && (GAME == 0 || p.n_waste == m.n_waste))
-                fast = f;
-        }
+        const int fast = fast_profile(p, GAME);
         if (std_view && p.N == 5) {
             if (fast == 1) launch_step<GAME, F32, 5, true, 1>(p, grid, block, lds, s);
             else if (GAME == 0 && fast == 2) { if constexpr (GAME == 0) launch_step<GAME, F32, 5, true, 2>(p, grid, block, lds, s); }

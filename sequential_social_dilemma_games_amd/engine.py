@@ -175,13 +175,16 @@ class VecEngine(object):
         """How many independent env ranges rollout_random() enqueues on streams of its own (0 = automatic)."""
         _capi.check(self._L.ssd_set_rollout_chains(self._h, int(chains)), self._h)
 
-    def rollout_random(self, n_steps, obs, rew=None, done=None, reset_every=0, step0=0, num_actions=None, fused=False):
+    def rollout_random(self, n_steps, obs, rew=None, done=None, reset_every=0, step0=0, num_actions=None, fused=False,
+                       pipelined=False):
         """rollout.py:58-70 as ONE library call: `n_steps` random-action steps (plus a full reset whenever
         (step0 + k) % reset_every == 0) enqueued back to back.  obs / rew / done are device tensors with a leading ring
         dimension R: step k writes slot (step0 + k) % R  (obs u8 or f32 [R,E,N,V,V,3], rew i32 [R,E,N], done u8 [R,E,N]).
         Same launches as n_steps calls of step_random(); the host just stops being the bottleneck.
         fused=True: ONE kernel launch for the whole call (SSD_ROLLOUT_FUSED) -- every env stays in LDS / registers across
-        its steps; same results, uint8 observations only."""
+        its steps; same results, uint8 observations only.
+        pipelined=True: ask for SSD_ROLLOUT_PIPELINED (step k+1 starts env by env while step k's slower envs are still at
+        work; needs a ring of at least 2 slots and pays up to 2048 envs -- see include/ssd.h)."""
         torch, dev = self._torch()
         ring = int(obs.shape[0])
         if obs.dtype not in (torch.uint8, torch.float32):
@@ -194,7 +197,8 @@ class VecEngine(object):
         na = self.num_actions if num_actions is None else int(num_actions)
         _capi.check(self._L.ssd_rollout_random(self._h, na, int(n_steps), int(reset_every), int(step0), self._dp(obs), self._dp(rew),
                                                self._dp(done), ring, (_capi.SSD_OBS_F32 if obs.dtype == torch.float32 else 0) |
-                                               (_capi.SSD_ROLLOUT_FUSED if fused else 0),
+                                               (_capi.SSD_ROLLOUT_FUSED if fused else 0) |
+                                               (_capi.SSD_ROLLOUT_PIPELINED if pipelined else 0),
                                                self._stream()), self._h)
         n_steps, reset_every, step0 = int(n_steps), int(reset_every), int(step0)
         last = None                                  # index of the last step of this call that a full reset preceded

@@ -39,6 +39,36 @@ def test_full_size_rollout_is_bit_exact_against_the_oracle(game):
     assert eng.status() == 0
 
 
+@pytest.mark.parametrize("game", [K.GAME_HARVEST, K.GAME_CLEANUP])
+def test_pipelined_rollout_under_load_is_bit_exact(game):
+    """SSD_ROLLOUT_PIPELINED at the largest batch it accepts of the shipped maps' order (2048 envs: configs[4]'s per-GPU
+    share): two launches in flight, every env's wave handing its state to the next step's wave through memory.  150 steps
+    with a reset in the middle; the last ring slots and the final state equal the oracle's, no wave timed out.  (A missing
+    wait before the hand-over flag shows up here and not with a few hundred envs.)"""
+    import torch
+    amap = K.HARVEST_MAP if game == K.GAME_HARVEST else K.CLEANUP_MAP
+    E, N, ring, every, steps = 2048, 5, 2, 97, 150
+    eng = VecEngine(game, amap, num_envs=E, num_agents=N, seed=12)
+    ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), seed=12)
+    obs = torch.zeros((ring, E, N, 15, 15, 3), dtype=torch.uint8, device="cuda")
+    rew = torch.zeros((ring, E, N), dtype=torch.int32, device="cuda")
+    eng.rollout_random(steps, obs, rew, None, reset_every=every, step0=0, pipelined=True)
+    want = {}
+    for k in range(steps):
+        if k % every == 0:
+            ora.reset()
+        _, o_obs, o_rew, _ = ora.step_random(want_obs=(k >= steps - ring))
+        want[k] = (o_obs, o_rew)
+    got_obs, got_rew = obs.cpu().numpy(), rew.cpu().numpy()
+    for k in range(steps - ring, steps):
+        np.testing.assert_array_equal(got_rew[k % ring], want[k][1], err_msg="rew of step %d" % k)
+        assert np.array_equal(got_obs[k % ring], want[k][0]), "observations of step %d differ" % k
+    a, b = eng.get_state(), ora.get_state()
+    for key in ("world", "pos", "orient", "episode", "t"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert eng.status() == 0
+
+
 def test_shard_invariance_and_determinism():
     """Seeds derive from the GLOBAL env index: 4096 envs in one handle == 4 handles of 1024 envs with
     env_index_base = 0, 1024, ...  (the partitioning of configs[3], on one GPU); and the same seed twice

@@ -495,6 +495,45 @@ def test_fused_rollout_specialisations(cfg):
     _fused_vs_oracle(eng, ora, E, N, 15, steps=31, every=10, ring=3)
 
 
+@pytest.mark.parametrize("game", [K.GAME_HARVEST, K.GAME_CLEANUP])
+@pytest.mark.parametrize("chains", [1, 2])
+def test_pipelined_rollout_matches_the_oracle(game, chains):
+    """SSD_ROLLOUT_PIPELINED: step launches alternate between two streams and each env's wave waits for that env's previous
+    step through a counter in device memory instead of stream order.  Same results as the oracle stepped call by call:
+    every ring slot, across resets in the middle of a call and across two calls; no wave ever gives up waiting."""
+    import torch
+    E, N, ring, every = 300, 5, 3, 11
+    eng = VecEngine(game, None, num_envs=E, num_agents=N, seed=5)
+    ora = pyoracle.Oracle(game, K.HARVEST_MAP if game == K.GAME_HARVEST else K.CLEANUP_MAP, E, N, G.default_lut(), seed=5)
+    obs = torch.zeros((ring, E, N, 15, 15, 3), dtype=torch.uint8, device="cuda")
+    rew = torch.zeros((ring, E, N), dtype=torch.int32, device="cuda")
+    done = torch.zeros((ring, E, N), dtype=torch.uint8, device="cuda")
+    eng.set_rollout_chains(chains)
+    total = 0
+    for n in (25, 1, 38):                                       # (a single step is not pipelined: nothing to overlap)
+        eng.rollout_random(n, obs, rew, done, reset_every=every, step0=total, pipelined=True)
+        want = {}
+        for k in range(total, total + n):
+            if k % every == 0:
+                ora.reset()
+            _, o_obs, o_rew, _ = ora.step_random()
+            want[k] = (o_obs, o_rew)
+        total += n
+        got_obs, got_rew = obs.cpu().numpy(), rew.cpu().numpy()
+        for k in range(max(total - ring, total - n), total):
+            np.testing.assert_array_equal(got_obs[k % ring], want[k][0], err_msg="obs of step %d" % k)
+            np.testing.assert_array_equal(got_rew[k % ring], want[k][1], err_msg="rew of step %d" % k)
+        a, b = eng.get_state(), ora.get_state()
+        for key in ("world", "pos", "orient", "episode", "t"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert eng.status() == 0
+    # afterwards the ordinary paths continue from the same state
+    o2, r2, _ = eng.step_random()
+    _, o_obs, o_rew, _ = ora.step_random()
+    np.testing.assert_array_equal(o2.cpu().numpy(), o_obs)
+    np.testing.assert_array_equal(r2.cpu().numpy(), o_rew)
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_rollout_random_edge_cases(fused):
     """n_steps = 0 is a no-op; reset_every = 1 resets before every step; more chains than envs; a ring longer than the

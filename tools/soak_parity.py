@@ -35,7 +35,9 @@ def main():
     t0 = time.time()
     checks = 0
     rsum = 0
-    ring = tuple(t.unsqueeze(0) for t in out)
+    R = int(os.environ.get("SOAK_RING", "1"))                  # output ring slots (pipelined launches need >= 2)
+    import torch
+    ring = tuple(t.unsqueeze(0) for t in out) if R == 1 else tuple(torch.zeros((R,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in out)
     if how != "step":
         assert 1000 % Kc == 0
         eng.set_rollout_chains(2 if how == "chains" else 1)
@@ -49,7 +51,8 @@ def main():
             obs, rew, _ = eng.step_random(out=out)
         elif s % Kc == 0:                                      # the Kc steps up to the next checkpoint in one library call
             eng.rollout_random(Kc, *ring, reset_every=1000, step0=s, fused=(how == "fused"))
-            obs, rew = out[0], out[1]
+            last = (s + Kc - 1) % R
+            obs, rew = ring[0][last], ring[1][last]
         _, o_obs, o_rew, _ = ora.step_random(want_obs=want_obs)
         if want_obs:
             r = rew.cpu().numpy()
