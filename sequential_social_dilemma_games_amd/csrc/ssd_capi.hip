@@ -514,9 +514,6 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
     SSD_HIP(env, hipSetDevice(env->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     uint8_t *o = static_cast<uint8_t *>(obs);
-    // Envs are independent, so a rollout is as many independent launch chains as we like.  Two chains on two streams
-    // (each enqueued by its own host thread) keep the GPU busy while the other chain's kernel drains and the next one is
-    // dispatched -- the ~2 us per launch that a single chain of 9 us kernels cannot hide.  SSD_ROLLOUT_CHAINS overrides.
     // Pipelined launches (SSD_ROLLOUT_PIPELINED; SSD_ROLLOUT_PIPELINE=1 / 0 in the environment forces / forbids them): only the
     // known maps' uint8 kernels have the variant, consecutive steps must not share an output slot, and the launches that can
     // be in flight together must fit on the device with room to spare -- a wave that waits for its env's previous pass must
@@ -538,6 +535,9 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
         static const bool tight = [] { const char *v = getenv("SSD_PIPELINE_TIGHT"); return v && atoi(v) != 0; }();   // tuning: no margin
         if (2LL * env->E * (tight ? 4 : 5) > cap * 4) pipelined = false;
     }
+    // Envs are independent, so a rollout is as many independent launch chains as we like.  Two chains on two streams
+    // (each enqueued by its own host thread) keep the GPU busy while the other chain's kernel drains and the next one is
+    // dispatched -- the ~2 us per launch that a single chain of 9 us kernels cannot hide.  SSD_ROLLOUT_CHAINS overrides.
     static const int forced = [] { const char *v = getenv("SSD_ROLLOUT_CHAINS"); return v ? atoi(v) : 0; }();
     int chains = env->rollout_chains > 0 ? env->rollout_chains : forced > 0 ? forced : (env->E >= 2048 && n_steps >= 16 ? 2 : 1);
     if ((flags & SSD_ROLLOUT_FUSED) && env->rollout_chains <= 0 && forced <= 0) chains = 1;   // one launch already covers the whole rollout
