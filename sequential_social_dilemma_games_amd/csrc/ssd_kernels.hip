@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             const uint32_t want = p.pipe_seq - 1u;
             uint32_t spins = 0;
             while (__hip_atomic_load(p.pipe_flags + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(8);
                 if (++spins > 40000u) { pipe_timeout = true; break; }     // (tens of milliseconds: never in a healthy run)
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // (compiler ordering; the state loads below are coherent ones)
