@@ -483,7 +483,8 @@ static int rollout_chain(ssd_env *env, int chain, bool pipelined, int e_begin, i
             }
             p.mode = ssd::kModeStep; p.rotate = 1; p.num_actions_random = num_actions;
             p.rew = rew ? rew + slot * en : nullptr; p.done = done ? done + slot * en : nullptr;
-            p.pipe_flags = env->pipe_flags; p.pipe_seq = ++seq;
+            static const uint32_t rotate = [] { const char *v = getenv("SSD_PIPE_ROTATE"); return v ? (uint32_t)atoi(v) : 0u; }();   // test knob
+            p.pipe_flags = env->pipe_flags; p.pipe_seq = ++seq; p.pipe_rotate = rotate;
             ssd::launch(p, env->game, st[(seq - 1) & 1]);
         }
         if (!join()) return SSD_E_DEVICE;

@@ -74,6 +74,8 @@ struct Params {
     // A launch with pipe_flags waits, env by env, for pass pipe_seq - 1 instead of relying on stream order (see ssd_capi.hip).
     uint32_t *pipe_flags;
     uint32_t pipe_seq;
+    uint32_t pipe_rotate;          // test knob (SSD_PIPE_ROTATE): shift the env -> workgroup mapping by this many workgroups per launch,
+                                   // so that an env's consecutive steps run on different XCDs (workgroups go round-robin to XCDs)
 };
 
 size_t lds_bytes(const Params &p, int envs_per_block, bool f32);

@@ -268,7 +268,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     uint8_t *s_occ = s_beam + S;
     uint8_t *s_view = roll ? s_occ + S + A0 : s_world;              // what the observations read: world <- agents <- beams
 
-    const int e = a_e_begin + blockIdx.x * a_epb + wv;      // (a_epb = blockDim.x / 64, without the implicit-argument load)
+    int blk = blockIdx.x;
+    if constexpr (PIPE) blk = (int)((blockIdx.x + p.pipe_seq * p.pipe_rotate) % gridDim.x);   // (test knob; 0 = identity)
+    const int e = a_e_begin + blk * a_epb + wv;             // (a_epb = blockDim.x / 64, without the implicit-argument load)
     constexpr int mode = MODE;                               // compile-time: step / reset / observe
     bool active = e < a_E;                                   // wave-uniform
     if (active && mode == kModeReset && p.mask) active = p.mask[e] != 0;

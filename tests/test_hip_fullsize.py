@@ -69,6 +69,22 @@ def test_pipelined_rollout_under_load_is_bit_exact(game):
     assert eng.status() == 0
 
 
+def test_pipelined_handover_between_xcds():
+    """The pipelined kernels hand an env's state from one wave to the next through memory with agent-scope accesses.
+    SSD_PIPE_ROTATE shifts the env -> workgroup mapping by one workgroup per launch, so that every env changes XCD (and
+    with it the L2 it sits behind) at every step: still bit-exact against the oracle.  (A process of its own: the knob is
+    read once per process.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSD_PIPE_ROTATE="1", SSD_ROLLOUT_PIPELINE="1", SOAK_RING="2")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_parity.py"), "cleanup", "1024", "400", "50", "chains"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "soak ok" in out, out[-2000:]
+
+
 def test_shard_invariance_and_determinism():
     """Seeds derive from the GLOBAL env index: 4096 envs in one handle == 4 handles of 1024 envs with
     env_index_base = 0, 1024, ...  (the partitioning of configs[3], on one GPU); and the same seed twice
