@@ -367,8 +367,10 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
     if ((rc = upload(env, &d32, lut))) return bail(rc);
     p.lut = d32;
     {   // float32 of the reference's float64 normalisation (map_env.py:199), one entry per byte value
-        std::vector<float> f32lut(256);
-        for (int x = 0; x < 256; ++x) f32lut[x] = (float)(((double)x - 128.0) / 255.0);
+        // ... applied to the colour table: glyph -> (r, g, b, 0) as float32, one 16-byte entry per glyph
+        std::vector<float> f32lut(128 * 4, 0.0f);
+        for (int g = 0; g < 128; ++g)
+            for (int c = 0; c < 3; ++c) f32lut[4 * g + c] = (float)(((double)((lut[g] >> (8 * c)) & 0xFFu) - 128.0) / 255.0);
         float *df;
         if ((rc = upload(env, &df, f32lut))) return bail(rc);
         p.f32lut = df;

@@ -55,7 +55,7 @@ struct Params {
     const uint32_t *apple_cells;   // [n_apple] 'A' (harvest.py:22-26) / 'B' (cleanup.py:53-54) cells, row-major
     const uint32_t *waste_cells;   // [n_waste] 'H' or 'R' cells (cleanup.py:59-60), row-major
     const uint32_t *lut;           // [128]   r | g << 8 | b << 16
-    const float *f32lut;           // [256]   float32((x - 128.0) / 255.0), exact (host-built)
+    const float *f32lut;           // [128][4] glyph -> float32((channel - 128.0) / 255.0) of r, g, b (exact, host-built), 0
     const uint64_t *thr_ca;        // [n_thr] Cleanup apple thresholds by #'H'
     const uint64_t *thr_cw;        // [n_thr] Cleanup waste thresholds by #'H'
     uint32_t thr_h32[4];           // Harvest apple thresholds by min(#neighbour apples, 3): rand < p  <=>  u32 draw < thr

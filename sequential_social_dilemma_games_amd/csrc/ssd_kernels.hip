@@ -170,7 +170,7 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
 
 // ---------------------------------------------------------------------------------------------
 // LDS layout of one workgroup: per wave (= per env)  lut[128] u32 | scratch[64] u32 |
-// f32lut[256] (float32-obs kernels only) | apron[A0] | world[S] | apron[A1] | beam[S] | occ[S]
+// glyph -> 3 floats table [128][4] (float32-obs kernels only) | apron[A0] | world[S] | apron[A1] | beam[S] | occ[S]
 // Waves never read each other's LDS, so the kernel has no workgroup barrier.
 //
 // Grid layout (HBM and LDS alike): row stride WP = W + view_len, the view_len bytes after each row hold the
@@ -183,7 +183,7 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
 // which then carries the aprons) instead of overwriting the world layer in place.
 __host__ size_t lds_bytes(const Params &p, int envs_per_block, bool f32) {
     const int layers = p.mode == kModeRollout ? 4 : 3;
-    return (size_t)envs_per_block * (128 * 4 + 256 + (f32 ? 256 * 4 : 0) + (size_t)p.A0 + (size_t)p.A1 + layers * (size_t)p.S);
+    return (size_t)envs_per_block * (128 * 4 + 256 + (f32 ? 128 * 16 : 0) + (size_t)p.A0 + (size_t)p.A1 + layers * (size_t)p.S);
 }
 
 // Envs (= waves) per workgroup.  Waves are independent, so this only changes dispatch granularity; measured on
@@ -259,11 +259,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     // envs -- a reset pass whose (unrotated) observations replace the step's rows.  Laid out like a plain step.
     constexpr bool auto_mode = MODE == kModeStepAuto;
     constexpr bool stepping = MODE == kModeStep || auto_mode;       // the launch takes actions
-    uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + (size_t)wv * (512 + 256 + (F32 ? 1024 : 0) + (size_t)A0 + (size_t)A1 +
+    uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + (size_t)wv * (512 + 256 + (F32 ? 2048 : 0) + (size_t)A0 + (size_t)A1 +
                                                                             (roll ? 4 : 3) * (size_t)S));
     uint32_t *s_tmp = s_lut + 128;                                  // 64 list entries of scratch (respawn compaction)
     float *s_f32 = reinterpret_cast<float *>(s_lut + 192);          // float32-observation kernels only
-    uint8_t *s_world = reinterpret_cast<uint8_t *>(s_lut + 192 + (F32 ? 256 : 0)) + (roll ? 0 : A0);
+    uint8_t *s_world = reinterpret_cast<uint8_t *>(s_lut + 192 + (F32 ? 512 : 0)) + (roll ? 0 : A0);
     uint8_t *s_beam = s_world + S + (roll ? 0 : A1);
     uint8_t *s_occ = s_beam + S;
     uint8_t *s_view = roll ? s_occ + S + A0 : s_world;              // what the observations read: world <- agents <- beams
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // glyph -> RGB table of the observation phase, one copy per wave
         const uint32_t lut_a = a_lut[lane], lut_b = a_lut[lane + 64];
         const bool obs_f32 = F32 && a_obs;
-        float4 flut = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (obs_f32) flut = reinterpret_cast<const float4 *>(p.f32lut)[lane];
+        float4 flut = make_float4(0.f, 0.f, 0.f, 0.f), flut_b = flut;       // glyph -> (r, g, b, -) as float32, entries lane and lane + 64
+        if (obs_f32) { flut = reinterpret_cast<const float4 *>(p.f32lut)[lane]; flut_b = reinterpret_cast<const float4 *>(p.f32lut)[lane + 64]; }
         // static cell lists of the map: the first 64 * kLR entries live in registers
         uint32_t alist[kLR], wlist[kLR];
 #pragma unroll
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         }
         uint32_t key = rfl(hdr.x), t = rfl(hdr.y), episode = rfl(hdr.z);
         s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b;
-        if (obs_f32) reinterpret_cast<float4 *>(s_f32)[lane] = flut;
+        if (obs_f32) { reinterpret_cast<float4 *>(s_f32)[lane] = flut; reinterpret_cast<float4 *>(s_f32)[lane + 64] = flut_b; }
         uint32_t status = pipe_timeout ? kStPipeTimeout : 0u;
         uint32_t cell = areg & 0xFFFFu, orient = mode == kModeReset ? 2u : (areg >> 16) & 3u;   // lane = agent index
         int rew = 0;
@@ -1107,6 +1107,50 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     a_s0 = (uint32_t)((int)cell - v * (WP + 1) + (a_k >= 2 ? (V - 1) * (WP + 1) : 0));
                 }
                 const uint32_t world_lds = (uint32_t)(uintptr_t)(lds_u8 *)s_view;       // LDS byte address of grid cell 0
+                if (F32 && a_obs && VV * 3 >= 4) {
+                    // float32 observations: an agent's block is V*V*3 floats (2700 B).  Lane l of store k4 writes the four
+                    // floats k4*256 + 4l .. +3 of it, so that every store instruction covers 1 KB of contiguous memory --
+                    // with a cell's three floats kept together (48 B per lane, 16 B per store) every 64-byte line was written
+                    // by three instructions, 16 B at a time, and the L2's write transactions, not HBM, bounded the mode
+                    // (17.1 us per 4096-env step).  Four consecutive floats span two cells: both are looked up (glyph, then the
+                    // glyph's float triple), and the lane picks its four of their six floats by f0 % 3.  The lane that would
+                    // run past the block's end starts four floats before the end instead (same values, written twice).
+                    const int nf = VV * 3, n_st = (nf + 255) >> 8;
+                    float *base_env = reinterpret_cast<float *>(a_obs) + (slot_en + (size_t)e * N) * (size_t)nf;
+                    for (int k4 = 0; k4 < n_st; ++k4) {
+                        const int f_raw = k4 * 256 + 4 * lane;
+                        const bool on = f_raw < nf;
+                        const int f0 = f_raw > nf - 4 ? nf - 4 : f_raw;
+                        const int c0 = (int)(((uint32_t)f0 * 21846u) >> 16);             // f0 / 3 (f0 < 2^15)
+                        const int r = f0 - 3 * c0;
+                        int M0[2], M1[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int pp = c0 + q;
+                            const int i = STD ? pp / 15 : (int)(((uint32_t)pp * p.v_magic16) >> 16), j = pp - i * V;
+                            M0[q] = i * WP + j;
+                            M1[q] = j * WP + (V - 1 - i);
+                        }
+                        const bool r0 = r == 0, r1 = r == 1;
+                        for (int ag = 0; ag < N; ++ag) {
+                            const uint32_t k = rl(a_k, ag);
+                            const int s0 = (int)(rl(a_s0, ag) + world_lds);
+                            const int sgn = k >= 2 ? -1 : 1;
+                            float4 t[2];
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                const uint32_t ad = (uint32_t)(s0 + sgn * ((k & 1) ? M1[q] : M0[q]));
+                                t[q] = reinterpret_cast<const float4 *>(s_f32)[*(lds_u8 *)(uintptr_t)ad];
+                            }
+                            f32x4_t o;
+                            o.x = r0 ? t[0].x : r1 ? t[0].y : t[0].z;
+                            o.y = r0 ? t[0].y : r1 ? t[0].z : t[1].x;
+                            o.z = r0 ? t[0].z : r1 ? t[1].x : t[1].y;
+                            o.w = r0 ? t[1].x : r1 ? t[1].y : t[1].z;
+                            if (on) store16_wt(base_env + (size_t)ag * nf, (uint32_t)f0 * 4u, o, p.obs_wt != 0);
+                        }
+                    }
+                } else
                 for (int base = 0; base < VV; base += 256) {
                     // A lane renders 4 consecutive cells = one 12-byte store.  V*V is not a multiple of 4 (225 = 56*4 + 1):
                     // the lane holding the leftover cells starts 4 cells before the end instead, re-rendering up to 3
@@ -1182,19 +1226,20 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                             for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[q]) : "v"(L0[q]), "v"(sgn), "s"(s0));
                         }
                         // a cell outside the map reads the '0' of the row padding / aprons (utility_funcs.py:94-114)
+                        uint32_t gl[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) px[q] = s_lut[*(lds_u8 *)(uintptr_t)addr[q]];
+                        for (int q = 0; q < 4; ++q) gl[q] = *(lds_u8 *)(uintptr_t)addr[q];
                         const size_t cell0 = (size_t)ag * VV + pp0;                     // first of this lane's cells within the env
                         if (obs_f32) {
-                            // float32 mode: 3 floats per cell through the exact byte -> float table, 48 contiguous
+                            // float32 mode: 3 floats per cell through the glyph -> float32 colour table (one 16-byte LDS read
+                            // per cell; the table holds float32 of the reference's float64 values, exact), 48 contiguous
                             // bytes per lane (three 16-byte stores; an agent block starts at a multiple of 2700 B)
                             float *dstf = reinterpret_cast<float *>(a_obs) + ((slot_en + (size_t)e * N) * VV + cell0) * 3;
                             float f[12];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                f[q * 3 + 0] = s_f32[px[q] & 0xFFu];
-                                f[q * 3 + 1] = s_f32[(px[q] >> 8) & 0xFFu];
-                                f[q * 3 + 2] = s_f32[(px[q] >> 16) & 0xFFu];
+                                const float4 v = reinterpret_cast<const float4 *>(s_f32)[gl[q]];
+                                f[q * 3 + 0] = v.x; f[q * 3 + 1] = v.y; f[q * 3 + 2] = v.z;
                             }
                             if (VV >= 4) {
                                 if (lane_on) {
@@ -1212,6 +1257,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                             }
                             continue;
                         }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) px[q] = s_lut[gl[q]];
                         uint8_t *dst = out_env + (size_t)ag * VV * 3 + off3;
                         if (VV >= 4) {
                             if (lane_on) {

@@ -413,6 +413,25 @@ def test_float32_observation_mode_is_the_cast_of_the_reference_float64():
         assert torch.equal(fa[0][~mask.bool()], before[~mask.bool()])          # rows of envs that were not reset stay
 
 
+@pytest.mark.parametrize("view_len", [0, 1, 2, 4, 9, 15])
+def test_float32_observations_of_other_view_sizes(view_len):
+    """The float32 stores are laid out by float index (four consecutive floats of an agent's block per lane and store, so a
+    store instruction covers contiguous memory): views whose V*V*3 is below one store (3, 27, 75 floats), around one or a
+    few (243, 1083) and the largest (31 x 31: 2883 floats, 12 stores per agent) against the uint8 observations."""
+    rng = np.random.default_rng(100 + view_len)
+    amap = _random_map(rng, 11, 13, K.GAME_CLEANUP, 8)
+    E, N = 37, 6
+    a = VecEngine(K.GAME_CLEANUP, amap, num_envs=E, num_agents=N, seed=3, view_len=view_len)
+    b = VecEngine(K.GAME_CLEANUP, amap, num_envs=E, num_agents=N, seed=3, view_len=view_len)
+    fa, ub = a.alloc_outputs(float32=True), b.alloc_outputs()
+    a.reset(obs=fa[0]); b.reset(obs=ub[0])
+    for _ in range(8):
+        a.step_random(out=fa); b.step_random(out=ub)
+        want = ((ub[0].cpu().numpy().astype(np.float64) - 128.0) / 255.0).astype(np.float32)
+        assert np.array_equal(fa[0].cpu().numpy(), want)
+    assert a.status() == 0 and b.status() == 0
+
+
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("game", [K.GAME_HARVEST, K.GAME_CLEANUP])
 def test_rollout_random_is_the_same_launches_as_step_by_step(game, fused):
