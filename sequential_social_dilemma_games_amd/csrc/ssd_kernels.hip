@@ -1377,8 +1377,8 @@ static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipS
 void launch(const Params &p_in, int game, void *stream) {
     Params p = p_in;
     static const int forced_wt = [] { const char *v = getenv("SSD_OBS_WT"); return v ? atoi(v) : -1; }();   // tuning override
-    // per launch (rollouts run two launches at a time); float32 observations are 4x the bytes: bandwidth-bound from the start
-    p.obs_wt = forced_wt >= 0 ? forced_wt : (((p.E - p.e_begin) <= 16384 && !p.obs_f32) ? 1 : 0);
+    // per launch (rollouts run two launches at a time); float32 observations are 4x the bytes: a quarter of the envs
+    p.obs_wt = forced_wt >= 0 ? forced_wt : ((p.E - p.e_begin) <= (p.obs_f32 ? 4096 : 16384) ? 1 : 0);
     const bool f32 = p.obs && p.obs_f32;            // the float32-observation variant is a separate instantiation
     const int epb = envs_per_block(p, f32);
     const dim3 grid((p.E - p.e_begin + epb - 1) / epb), block(64 * epb);
