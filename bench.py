@@ -264,6 +264,17 @@ def main():
         if tkey and E == 4096 and args.agents is None and not args.obs_f32 and os.path.exists(tpath):
             res["roofline"]["traffic"] = json.load(open(tpath))[tkey]["hbm_bytes_per_launch"]
             res["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 PMC, same workload)"
+            # and what rocprofv3 --kernel-trace --stats says one launch of that kernel lasts (committed summary; tracing slows
+            # the dispatch path down, so this is the kernel's duration in that regime, not the unprofiled step time)
+            spath = os.path.join(REPO, "profiles", "r01_final_kernel_stats.csv" if args.game == "harvest" else "r01_final_cleanup_kernel_stats.csv")
+            if os.path.exists(spath):
+                import csv
+                for row in csv.DictReader(open(spath)):
+                    if "ssd_env_kernel<%d, 0, false, 5, true, 1>" % (0 if args.game == "harvest" else 1) in row["Name"]:
+                        res["roofline"]["rocprof_avg_kernel_us"] = float(row["AverageNs"]) / 1e3
+                        res["roofline"]["rocprof_source"] = ("profiles/%s: per launch of %d envs under rocprofv3 --kernel-trace (which "
+                                                             "adds per-dispatch overhead: the same run's steps take 11.9 us there)" % (
+                                                                 os.path.basename(spath), E // chains))
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(game, amap, n_agents)
         print(json.dumps(res), file=real_stdout)
