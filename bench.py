@@ -154,7 +154,7 @@ def main():
     use_rollout = not args.per_step_calls
     chains = 1
     if use_rollout:                                # env ranges the library steps on streams of its own (envs are independent)
-        chains = args.chains if args.chains > 0 else (1 if args.pipelined else 2 if E >= 2048 else 1)   # (a pipelined chain overlaps its own launches)
+        chains = args.chains if args.chains > 0 else (1 if args.pipelined or E < 2048 else 3 if 6144 <= E <= 24576 else 2)   # (a pipelined chain overlaps its own launches)
         eng.set_rollout_chains(chains)
 
     def run_steps(k0, n):

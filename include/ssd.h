@@ -133,7 +133,7 @@ int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, voi
 int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32_t reset_every, int32_t step0,
                        void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream);
 
-/* Number of chains ssd_rollout_random uses: 1..8, or 0 = automatic (2 from 2048 envs on, else 1). */
+/* Number of chains ssd_rollout_random uses: 1..8, or 0 = automatic (1 below 2048 envs, 3 from 6144 to 24576, else 2). */
 int ssd_set_rollout_chains(ssd_env *env, int32_t chains);
 
 /* Observation of the current state without stepping (the per-agent part of map_env.py:189-199). */

@@ -542,7 +542,7 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
     // (each enqueued by its own host thread) keep the GPU busy while the other chain's kernel drains and the next one is
     // dispatched -- the ~2 us per launch that a single chain of 9 us kernels cannot hide.  SSD_ROLLOUT_CHAINS overrides.
     static const int forced = [] { const char *v = getenv("SSD_ROLLOUT_CHAINS"); return v ? atoi(v) : 0; }();
-    int chains = env->rollout_chains > 0 ? env->rollout_chains : forced > 0 ? forced : (env->E >= 2048 && n_steps >= 16 ? 2 : 1);
+    int chains = env->rollout_chains > 0 ? env->rollout_chains : forced > 0 ? forced : (n_steps < 16 || env->E < 2048 ? 1 : (env->E >= 6144 && env->E <= 24576) ? 3 : 2);   // measured: profiles/r01_sweep_envs.txt
     if ((flags & SSD_ROLLOUT_FUSED) && env->rollout_chains <= 0 && forced <= 0) chains = 1;   // one launch already covers the whole rollout
     if (pipelined && env->rollout_chains <= 0 && forced <= 0) chains = 1;   // a pipelined chain overlaps its own launches (measured: 1 beats 2)
     if (chains > 8) chains = 8;
