@@ -64,7 +64,8 @@ enum {
                                 of the whole previous launch -- step k+1 starts env by env while step k's slower envs are still at
                                 work.  Same launches, same results.  Honoured when a map-specific uint8 kernel runs (the shipped
                                 and the enlarged maps), ring >= 2 (consecutive steps must not share an output slot) and two launches' waves fit on
-                                the device with a fifth of it to spare (up to ~3200 envs of the shipped maps on MI355X); ignored otherwise.  It pays while the
+                                the device with a fifth of it to spare (up to ~3200 envs of the shipped maps on MI355X); ignored otherwise, and while another handle's
+                                pipelined rollout is in flight on the device.  It pays while the
                                 device has room to spare: 2048 envs 5.7 -> 4.8 us per step, no gain at 4096.  A wave that waits in
                                 vain (tens of ms: the device is oversubscribed by other work) sets SSD_ST_PIPE_TIMEOUT. */
     SSD_OBS_F32 = 1u << 2    /* obs points at float32 [E,N,V,V,3] instead of uint8: the normalisation of map_env.py:199

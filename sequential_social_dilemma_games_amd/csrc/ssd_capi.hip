@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -40,6 +41,7 @@ struct ssd_env {
     std::vector<hipStream_t> chain_streams;
     std::vector<hipEvent_t> chain_events;
     hipEvent_t fork_event = nullptr;
+    hipEvent_t pipe_done = nullptr;   // recorded after this handle's last pipelined rollout
     // pipelined rollouts: per-env pass counters, and per chain a second stream (launches alternate) with its events
     uint32_t *pipe_flags = nullptr;
     struct ChainPipe { hipStream_t sb = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr; };
@@ -50,6 +52,11 @@ struct ssd_env {
 };
 
 namespace {
+
+// One pipelined rollout per device at a time (within this process): the room-to-spare rule of ssd_rollout_random counts one
+// handle's launches.  A handle asking while another handle's pipelined rollout is still in flight gets plain launches.
+struct PipeOwners { std::mutex mu; ssd_env *owner[64] = {}, *enqueuing[64] = {}; hipEvent_t done[64] = {}; };
+PipeOwners g_pipe_owners;
 
 #define SSD_HIP(env, call)                                                                      \
     do {                                                                                        \
@@ -392,6 +399,13 @@ int ssd_destroy(ssd_env *env) {
     for (hipStream_t cs : env->chain_streams) (void)hipStreamDestroy(cs);
     for (hipEvent_t ce : env->chain_events) (void)hipEventDestroy(ce);
     if (env->fork_event) (void)hipEventDestroy(env->fork_event);
+    {
+        std::lock_guard<std::mutex> lk(g_pipe_owners.mu);
+        const int d = env->device & 63;
+        if (g_pipe_owners.owner[d] == env) { g_pipe_owners.owner[d] = nullptr; g_pipe_owners.done[d] = nullptr; }
+        if (g_pipe_owners.enqueuing[d] == env) g_pipe_owners.enqueuing[d] = nullptr;
+    }
+    if (env->pipe_done) (void)hipEventDestroy(env->pipe_done);
     for (auto &cp : env->chain_pipe) {
         if (cp.sb) (void)hipStreamDestroy(cp.sb);
         if (cp.ev_a) (void)hipEventDestroy(cp.ev_a);
@@ -544,6 +558,16 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
     static const int forced = [] { const char *v = getenv("SSD_ROLLOUT_CHAINS"); return v ? atoi(v) : 0; }();
     int chains = env->rollout_chains > 0 ? env->rollout_chains : forced > 0 ? forced : (n_steps < 16 || env->E < 2048 ? 1 : (env->E >= 6144 && env->E <= 24576) ? 3 : 2);   // measured: profiles/r01_sweep_envs.txt
     if ((flags & SSD_ROLLOUT_FUSED) && env->rollout_chains <= 0 && forced <= 0) chains = 1;   // one launch already covers the whole rollout
+    if (pipelined) {
+        if (!env->pipe_done) SSD_HIP(env, hipEventCreateWithFlags(&env->pipe_done, hipEventDisableTiming));
+        std::lock_guard<std::mutex> lk(g_pipe_owners.mu);
+        const int d = env->device & 63;
+        if ((g_pipe_owners.enqueuing[d] && g_pipe_owners.enqueuing[d] != env) ||
+            (g_pipe_owners.owner[d] && g_pipe_owners.owner[d] != env && hipEventQuery(g_pipe_owners.done[d]) == hipErrorNotReady))
+            pipelined = false;                                      // another handle's pipelined rollout is being enqueued or still in flight
+        else
+            g_pipe_owners.owner[d] = g_pipe_owners.enqueuing[d] = env, g_pipe_owners.done[d] = env->pipe_done;
+    }
     if (pipelined && env->rollout_chains <= 0 && forced <= 0) chains = 1;   // a pipelined chain overlaps its own launches (measured: 1 beats 2)
     if (chains > 8) chains = 8;
     if (chains > env->E) chains = env->E;
@@ -551,6 +575,11 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
     if (chains <= 1) {
         int rc = rollout_chain(env, 0, pipelined, 0, env->E, num_actions, n_steps, reset_every, step0, o, rew, done, ring, flags, s);
         if (rc) env->err = "kernel launch failed in ssd_rollout_random";
+        if (pipelined) {
+            (void)hipEventRecord(env->pipe_done, s);
+            std::lock_guard<std::mutex> lk(g_pipe_owners.mu);
+            g_pipe_owners.enqueuing[env->device & 63] = nullptr;
+        }
         return rc;
     }
     while ((int)env->chain_streams.size() < chains - 1) {
@@ -577,6 +606,11 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
     for (int c = 1; c < chains; ++c) {
         SSD_HIP(env, hipEventRecord(env->chain_events[c - 1], env->chain_streams[c - 1]));
         SSD_HIP(env, hipStreamWaitEvent(s, env->chain_events[c - 1], 0));
+    }
+    if (pipelined) {
+        (void)hipEventRecord(env->pipe_done, s);
+        std::lock_guard<std::mutex> lk(g_pipe_owners.mu);
+        g_pipe_owners.enqueuing[env->device & 63] = nullptr;
     }
     for (int c = 0; c < chains; ++c)
         if (rcs[c]) { env->err = "kernel launch failed in ssd_rollout_random"; return rcs[c]; }

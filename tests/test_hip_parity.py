@@ -553,6 +553,33 @@ def test_pipelined_rollout_matches_the_oracle(game, chains):
     np.testing.assert_array_equal(r2.cpu().numpy(), o_rew)
 
 
+def test_two_handles_asking_for_pipelined_rollouts():
+    """Only one handle per device pipelines at a time (the room-to-spare rule counts one handle's launches): a second handle
+    that asks while the first one's rollout is still in flight gets plain launches.  Either way both are bit-exact."""
+    import torch
+    E, N, ring, steps = 1024, 5, 2, 60
+    engs = [VecEngine(g, None, num_envs=E, num_agents=N, seed=31 + g) for g in (K.GAME_HARVEST, K.GAME_CLEANUP)]
+    oras = [pyoracle.Oracle(g, K.HARVEST_MAP if g == K.GAME_HARVEST else K.CLEANUP_MAP, E, N, G.default_lut(), seed=31 + g)
+            for g in (K.GAME_HARVEST, K.GAME_CLEANUP)]
+    bufs = [(torch.zeros((ring, E, N, 15, 15, 3), dtype=torch.uint8, device="cuda"),
+             torch.zeros((ring, E, N), dtype=torch.int32, device="cuda")) for _ in engs]
+    for rep in range(2):
+        for eng, (obs, rew) in zip(engs, bufs):                  # enqueued back to back: the second call finds the first in flight
+            eng.rollout_random(steps, obs, rew, None, reset_every=25, step0=rep * steps, pipelined=True)
+        for eng, ora, (obs, rew) in zip(engs, oras, bufs):
+            for k in range(rep * steps, (rep + 1) * steps):
+                if k % 25 == 0:
+                    ora.reset()
+                _, o_obs, o_rew, _ = ora.step_random(want_obs=(k == (rep + 1) * steps - 1))
+            last = ((rep + 1) * steps - 1) % ring
+            np.testing.assert_array_equal(rew[last].cpu().numpy(), o_rew)
+            assert np.array_equal(obs[last].cpu().numpy(), o_obs)
+            a, b = eng.get_state(), ora.get_state()
+            for key in ("world", "pos", "orient", "episode", "t"):
+                np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+            assert eng.status() == 0
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_rollout_random_edge_cases(fused):
     """n_steps = 0 is a no-op; reset_every = 1 resets before every step; more chains than envs; a ring longer than the
