@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("SSD_LIB_PATH") or os.path.join(_PKG, "libssd_hip.so")
 
 SSD_OK, SSD_E_INVALID, SSD_E_DEVICE, SSD_E_NOMEM, SSD_E_STATE = 0, -1, -2, -3, -4
 SSD_HOST_PTRS, SSD_NO_ROTATE, SSD_OBS_F32, SSD_ROLLOUT_FUSED, SSD_AUTO_RESET, SSD_ROLLOUT_PIPELINED = 1, 2, 4, 8, 16, 32
-SSD_ST_BAD_ACTION, SSD_ST_NO_SPAWN, SSD_ST_MOVE_LOOKUP = 1, 2, 4
+SSD_ST_BAD_ACTION, SSD_ST_NO_SPAWN, SSD_ST_MOVE_LOOKUP, SSD_ST_PIPE_TIMEOUT = 1, 2, 4, 8
 ABI_VERSION = 1
 
 # every symbol include/ssd.h declares

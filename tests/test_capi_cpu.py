@@ -67,5 +67,7 @@ def test_python_constants_match_the_header():
 
     for name in ("SSD_HOST_PTRS", "SSD_NO_ROTATE", "SSD_OBS_F32", "SSD_ROLLOUT_FUSED", "SSD_AUTO_RESET", "SSD_ROLLOUT_PIPELINED"):
         assert getattr(_capi, name) == value(name), name
+    for name in ("SSD_ST_BAD_ACTION", "SSD_ST_NO_SPAWN", "SSD_ST_MOVE_LOOKUP", "SSD_ST_PIPE_TIMEOUT"):
+        assert getattr(_capi, name) == value(name), name
     assert value("SSD_OK") == 0 and value("SSD_E_DEVICE") == -2
     assert int(re.search(r"#define SSD_ABI_VERSION (\d+)", text).group(1)) == _capi.lib().ssd_abi_version()
