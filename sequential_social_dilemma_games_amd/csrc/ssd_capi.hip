@@ -480,8 +480,13 @@ static int rollout_chain(ssd_env *env, int chain, bool pipelined, int e_begin, i
         auto &cp = env->chain_pipe[chain];
         hipStream_t st[2] = {s, cp.sb};
         uint32_t seq = 0;
+        // test knob: the first launch of the call waits for a pass that never ran -- its waves must give up (bounded wait), set
+        // SSD_ST_PIPE_TIMEOUT and let the launch finish
+        static const bool test_stall = [] { const char *v = getenv("SSD_PIPE_TEST_STALL"); return v && atoi(v) != 0; }();
+        bool stall_once = test_stall;
         auto restart = [&]() -> bool {
-            seq = 0;
+            seq = stall_once ? 1 : 0;
+            stall_once = false;
             return hipMemsetAsync(env->pipe_flags + e_begin, 0, sizeof(uint32_t) * (size_t)(e_end - e_begin), s) == hipSuccess &&
                    hipEventRecord(cp.ev_a, s) == hipSuccess && hipStreamWaitEvent(cp.sb, cp.ev_a, 0) == hipSuccess;
         };

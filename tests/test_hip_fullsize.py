@@ -85,6 +85,36 @@ def test_pipelined_handover_between_xcds():
     assert r.returncode == 0 and "soak ok" in out, out[-2000:]
 
 
+def test_pipelined_wait_is_bounded():
+    """A wave of a pipelined launch that waits in vain gives up after a bounded number of polls, sets SSD_ST_PIPE_TIMEOUT and
+    lets its launch finish.  SSD_PIPE_TEST_STALL makes the first launch of a call wait for a pass that never ran (a process
+    of its own: the knob is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, time; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from sequential_social_dilemma_games_amd import _capi, constants as K\n"
+        "from sequential_social_dilemma_games_amd.engine import VecEngine\n"
+        "eng = VecEngine(K.GAME_HARVEST, None, num_envs=512, num_agents=5, seed=1)\n"
+        "obs = torch.zeros((2, 512, 5, 15, 15, 3), dtype=torch.uint8, device='cuda')\n"
+        "eng.reset()\n"
+        "torch.cuda.synchronize()\n"
+        "t0 = time.time()\n"
+        "eng.rollout_random(6, obs, None, None, reset_every=0, step0=0, pipelined=True)\n"
+        "torch.cuda.synchronize()\n"
+        "st = eng.status()\n"
+        "print('status', st, 'seconds', round(time.time() - t0, 3))\n"
+        "assert st & _capi.SSD_ST_PIPE_TIMEOUT, st\n"
+        "assert time.time() - t0 < 5.0\n" % root)
+    env = dict(os.environ, SSD_PIPE_TEST_STALL="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "status" in out, out[-2000:]
+
+
 def test_shard_invariance_and_determinism():
     """Seeds derive from the GLOBAL env index: 4096 envs in one handle == 4 handles of 1024 envs with
     env_index_base = 0, 1024, ...  (the partitioning of configs[3], on one GPU); and the same seed twice
