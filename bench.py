@@ -3,24 +3,30 @@
 
 A "step" is one pass of the hot path over one batch: every env of the batch advances one tick
 (device-drawn uniform random actions, as rollout.py:62-70), i.e. ONE launch of the fused
-kernel that moves agents, resolves conflicts, fires beams, respawns apples / waste, writes the
+kernel per env range that moves agents, resolves conflicts, fires beams, respawns apples / waste, writes the
 uint8 observations [E,N,15,15,3], rewards and dones.  Inputs (all env state) are resident in
 HBM when the timed region starts; `horizon` auto-resets are inside the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--game harvest|cleanup] [--envs E]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL); envs are sharded by global
-index with no data-path collective (weak scaling: --envs is per GPU).  `--gather` adds the
-optional RCCL all-gather of obs/rew over xGMI after every step.
+N > 1: one rank per GPU under torch.distributed.run (RCCL).  When the process is not already a rank of such a
+job (WORLD_SIZE unset) it starts the N ranks itself -- as a CHILD process, before this process has touched
+torch or the GPU -- and relays rank 0's JSON line.  Envs are sharded by global index with no data-path
+collective (weak scaling: --envs is per GPU).  `--gather` adds the optional RCCL all-gather of obs / rew
+over xGMI.  `--dry-run` is the launcher and sharding alone (gloo, no GPU, no engine): what the CPU test runs.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch (SURVEY.md
-8d: bytes/env-step x envs per launch) / average launch duration measured with HIP events on
-the launch stream over the timed region.  `cpu_baseline` = the C oracle (a port of the
-reference algorithm, oracle/ssd_oracle.c) timed on this host, one core, bounded sample.
+Prints ONE JSON line (rank 0).  ONE clock: `value`, `ms_per_step` and `roofline.frac` all come from the wall
+time of the K timed steps (barrier + synchronize on both sides, max over ranks); the HIP-event duration of
+the same region on the launch stream is reported next to it (`roofline.hip_event_us_per_step`).
+`roofline.achieved` = algorithmic bytes per step (bytes / env-step x envs) / time per step.
+`cpu_baseline` = the C oracle (a port of the reference algorithm, oracle/ssd_oracle.c) timed on this host,
+one core, bounded sample.  `configs` = the other single-GPU configurations of BASELINE.json, a few hundred
+steps each (N = 1 only).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,6 +36,7 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s achievable
 HORIZON = 1000               # run_scripts/train_baseline.py:131
+ROUND = "r02"
 
 
 def _oracle_worker(game, amap, n_agents, E, seconds, seed, out, idx):
@@ -47,7 +54,7 @@ def _oracle_worker(game, amap, n_agents, E, seconds, seed, out, idx):
     out[idx] = (steps, time.perf_counter() - t0)
 
 
-def cpu_baseline(game, amap, n_agents, target_s=12.0):
+def cpu_baseline(game, amap, n_agents, target_s=6.0):
     """The oracle on the host cores over a bounded sample of the same workload: one core (the headline `value` of this
     object), then every core the process may use (independent env shards, one thread each; the C call releases the GIL)."""
     import threading
@@ -78,22 +85,121 @@ def cpu_baseline(game, amap, n_agents, target_s=12.0):
     return res
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv):
+    """Start the N-rank job as a child process (torch.distributed.run, one rank per GPU) and relay rank 0's JSON line.
+    Runs before this process imports torch or touches the GPU; this process never becomes a rank itself."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.lstrip().startswith("{")]
+    rc = proc.returncode
+    if rc == 0 and not lines:
+        print("bench.py: the %d-rank job printed no JSON line" % n, file=sys.stderr)
+        rc = 1
+    if lines:
+        print(lines[-1])
+        sys.stdout.flush()
+    return rc
+
+
+GAMES = {"harvest": (0, "HARVEST_MAP", 5), "cleanup": (1, "CLEANUP_MAP", 5),
+         "harvest25x38": (0, "harvest_map_25x38", 5), "cleanup48x36": (1, "cleanup_map_48x36", 10)}
+
+
+def game_spec(name, agents=None):
+    from sequential_social_dilemma_games_amd import constants as K
+    game, m, n = GAMES[name]
+    amap = getattr(K, m)
+    if callable(amap):
+        amap = amap()
+    return game, amap, (n if agents is None else agents)
+
+
+def auto_chains(E, pipelined=False):
+    return 1 if pipelined or E < 2048 else 3 if 6144 <= E <= 24576 else 2    # (a pipelined chain overlaps its own launches)
+
+
+def time_rollout(torch, eng, ring, steps, warmup, step0=0, **kw):
+    """W untimed + K timed steps of eng.rollout_random (calls of at most 1000 steps).  Returns (wall s, HIP-event ms, enqueue s)."""
+    def run(k0, n):
+        for c0 in range(k0, k0 + n, 1000):
+            eng.rollout_random(min(1000, k0 + n - c0), ring[0], ring[1], ring[2], reset_every=HORIZON, step0=c0, **kw)
+    run(step0, warmup)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(step0 + warmup, steps)
+    ev1.record()
+    enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return wall, ev0.elapsed_time(ev1), enq
+
+
+def config_leg(torch, name, E, steps=400, warmup=50, obs_f32=False, pipelined=False, ring_slots=1):
+    """One of the other single-GPU workloads, stepped the way the headline is (ssd_rollout_random, automatic chains)."""
+    from sequential_social_dilemma_games_amd.engine import VecEngine
+    game, amap, n_agents = game_spec(name)
+    eng = VecEngine(game, amap, num_envs=E, num_agents=n_agents, seed=0)
+    out = eng.alloc_outputs(float32=obs_f32)
+    ring = tuple(t.unsqueeze(0) for t in out) if ring_slots <= 1 else \
+        tuple(torch.empty((ring_slots,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in out)
+    chains = auto_chains(E, pipelined)
+    eng.set_rollout_chains(chains)
+    wall, dev_ms, _ = time_rollout(torch, eng, ring, steps, warmup, pipelined=pipelined)
+    if eng.status() != 0:
+        raise SystemExit("device status word is non-zero (%s)" % name)
+    bytes_env = eng.algorithmic_bytes_per_env_step() + (n_agents * eng.V * eng.V * 3 * 3 if obs_f32 else 0)
+    us = wall * 1e6 / steps
+    res = {"workload": "%s %dx%d, %d agents, %d envs%s%s" % (name, eng.H, eng.W, n_agents, E, ", float32 obs" if obs_f32 else "",
+                                                            ", pipelined launches (ring %d)" % ring_slots if pipelined else ""),
+           "steps": steps, "warmup": warmup, "ms_per_step": us * 1e-3, "value": E * n_agents * steps / wall,
+           "bytes_per_env_step": bytes_env, "frac": bytes_env * E / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "hip_event_us_per_step": dev_ms * 1e3 / steps, "chains": chains}
+    eng.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--game", default="harvest", choices=["harvest", "cleanup", "harvest25x38", "cleanup48x36"])
+    ap.add_argument("--game", default="harvest", choices=sorted(GAMES))
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=None)
-    ap.add_argument("--gather", action="store_true", help="RCCL all-gather of obs/rew after every step")
+    ap.add_argument("--gather", action="store_true", help="RCCL all-gather of obs/rew (one collective per 32 steps)")
     ap.add_argument("--obs-f32", action="store_true", help="separate mode: the kernel writes float32 observations (4x the obs bytes)")
     ap.add_argument("--per-step-calls", action="store_true", help="one Python call per step instead of ssd_rollout_random")
     ap.add_argument("--pipelined", action="store_true", help="ask ssd_rollout_random for SSD_ROLLOUT_PIPELINED (needs --ring >= 2)")
     ap.add_argument("--ring", type=int, default=1, help="output ring slots of ssd_rollout_random (step k writes slot k %% ring)")
     ap.add_argument("--chains", type=int, default=0, help="env ranges stepped concurrently by ssd_rollout_random (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` legs (the other single-GPU workloads)")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline: no fused leg, call-overhead leg, configs, cpu baseline")
+    ap.add_argument("--dry-run", action="store_true", help="launcher + sharding only: gloo ranks, no GPU, no engine")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.no_extras:
+        args.no_cpu_baseline = args.no_configs = True
+
+    # ---- N ranks: if this process is not one of them yet, start them (as a child; nothing here has touched torch / HIP) ----
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     # The contract is ONE JSON line on stdout.  Libraries write to fd 1 behind Python's back (RCCL prints a
     # version banner when the first communicator is created), so park the real stdout and point fd 1 at
@@ -102,26 +208,35 @@ def main():
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
-    import torch
-    from sequential_social_dilemma_games_amd import constants as K
-    from sequential_social_dilemma_games_amd.engine import VecEngine
-
     from sequential_social_dilemma_games_amd import parallel
+    if args.dry_run:
+        dist, rank, world, local_rank = parallel.init_process_group("gloo")
+        if world != args.gpus:
+            raise SystemExit("--gpus %d but the job has %d ranks" % (args.gpus, world))
+        span = parallel.shard_range(world * args.envs, world, rank)
+        spans = [span]
+        if dist is not None:
+            spans = [None] * world
+            dist.all_gather_object(spans, span)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": world, "envs_per_gpu": args.envs,
+                              "shards": [list(s) for s in spans]}), file=real_stdout)
+            real_stdout.flush()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    import torch
+    from sequential_social_dilemma_games_amd.engine import VecEngine
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     dist, rank, world, local_rank = parallel.init_process_group("nccl")
     torch.cuda.set_device(local_rank)
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but the job has %d ranks (WORLD_SIZE)" % (args.gpus, world))
 
-    game, amap, n_agents = {
-        "harvest": (K.GAME_HARVEST, K.HARVEST_MAP, 5),
-        "cleanup": (K.GAME_CLEANUP, K.CLEANUP_MAP, 5),
-        "harvest25x38": (K.GAME_HARVEST, K.harvest_map_25x38(), 5),
-        "cleanup48x36": (K.GAME_CLEANUP, K.cleanup_map_48x36(), 10),
-    }[args.game]
-    if args.agents is not None:
-        n_agents = args.agents
+    game, amap, n_agents = game_spec(args.game, args.agents)
     E = args.envs                                  # per GPU (weak scaling); global batch = world * E
     eng, start, count = parallel.make_sharded_engine(game, amap, world * E, n_agents, rank, world,
                                                      local_rank=local_rank, seed=0)
@@ -129,7 +244,7 @@ def main():
     out = eng.alloc_outputs(float32=args.obs_f32)
     do_gather = bool(args.gather and dist is not None)
     GR = 32                                        # --gather: steps per collective (one RCCL all-gather moves GR steps' outputs)
-    gring = gbuf = None
+    gbuf = None
     if do_gather:                                  # the batched tensors every rank ends up with: [world, GR, E, ...]
         # two rings: while the collective of one is in flight on its own stream, the rollout fills the other
         grings = [(torch.empty((GR,) + tuple(out[0].shape), dtype=out[0].dtype, device=out[0].device),
@@ -147,14 +262,14 @@ def main():
         eng.step_random(out=out)
 
     # Without --gather / --per-step-calls the steps are enqueued by ssd_rollout_random: the same launches (one step
-    # kernel per step into the same output buffers, a full reset every HORIZON steps), issued by one library call per
-    # chunk instead of one Python call per step, so that the host never starves the 9 us kernels.
+    # kernel per step and env range into the same output buffers, a full reset every HORIZON steps), issued by one library
+    # call per chunk instead of one Python call per step, so that the host never starves the kernels.
     ring = tuple(t.unsqueeze(0) for t in out) if args.ring <= 1 else \
         tuple(torch.empty((args.ring,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in out)
     use_rollout = not args.per_step_calls
     chains = 1
     if use_rollout:                                # env ranges the library steps on streams of its own (envs are independent)
-        chains = args.chains if args.chains > 0 else (1 if args.pipelined or E < 2048 else 3 if 6144 <= E <= 24576 else 2)   # (a pipelined chain overlaps its own launches)
+        chains = args.chains if args.chains > 0 else auto_chains(E, args.pipelined)
         eng.set_rollout_chains(chains)
 
     def run_steps(k0, n):
@@ -206,26 +321,28 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)
     if eng.status() != 0:
         raise SystemExit("device status word is non-zero")
+    plain = use_rollout and not do_gather and not args.no_extras
+    # What one rollout call costs beyond its steps: the same K steps are timed again as part of ONE long call's rate
+    # (1000 steps, same launches); call_overhead_us = wall(K steps) - K x (per-step time of the long call).
+    long_us = None
+    if plain and args.steps < 1000:
+        lw, _, _ = time_rollout(torch, eng, ring, 1000, 0, step0=args.warmup + args.steps, pipelined=args.pipelined)
+        long_us = lw * 1e6 / 1000
     # Reported separately and labelled: the same K steps as ONE fused kernel launch -- every env
     # resident in LDS / registers across its steps (SSD_ROLLOUT_FUSED).  Not part of `value`.
-    fused_ms = None
-    if use_rollout and not args.obs_f32 and not do_gather:
-        eng.rollout_random(args.warmup, ring[0], ring[1], ring[2], reset_every=HORIZON, step0=0, fused=True)
-        torch.cuda.synchronize()
-        parallel.barrier(dist, local_rank)
-        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        f0.record()
-        eng.rollout_random(args.steps, ring[0], ring[1], ring[2], reset_every=HORIZON, step0=args.warmup, fused=True)
-        f1.record()
-        torch.cuda.synchronize()
-        fused_ms = f0.elapsed_time(f1)
+    fused_wall = fused_long_us = None
+    if plain and not args.obs_f32:
+        fused_wall, _, _ = time_rollout(torch, eng, ring, args.steps, args.warmup, fused=True)
+        if args.steps < 1000:
+            fw, _, _ = time_rollout(torch, eng, ring, 1000, 0, step0=args.warmup + args.steps, fused=True)
+            fused_long_us = fw * 1e6 / 1000
         if eng.status() != 0:
             raise SystemExit("device status word is non-zero")
     if dist is not None:
-        tw = torch.tensor([wall, dev_ms, fused_ms or 0.0], dtype=torch.float64, device="cuda")
+        tw = torch.tensor([wall, dev_ms, fused_wall or 0.0, enq], dtype=torch.float64, device="cuda")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(tw[0]), float(tw[1])
-        fused_ms = float(tw[2]) if fused_ms is not None else None
+        wall, dev_ms, enq = float(tw[0]), float(tw[1]), float(tw[3])
+        fused_wall = float(tw[2]) if fused_wall is not None else None
 
     if rank == 0:
         total_agent_steps = float(E) * n_agents * args.steps * world
@@ -233,48 +350,61 @@ def main():
         bytes_env = eng.algorithmic_bytes_per_env_step()
         if args.obs_f32:                           # the obs term becomes N * 2700 in this mode
             bytes_env += n_agents * eng.V * eng.V * 3 * 3
-        launch_us = dev_ms * 1e3 / args.steps      # average launch-to-launch duration of the step kernel on its stream
-        achieved = bytes_env * E / (launch_us * 1e-6) / 1e9
+        step_us = wall * 1e6 / args.steps           # THE clock: wall time of the K steps, per step
+        achieved = bytes_env * E / (step_us * 1e-6) / 1e9
         res = {
             "metric": "agent-env-steps/sec (random actions)", "value": value, "unit": "agent-env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_us * 1e-3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.obs_f32 else "u8", "data": "synthetic",
             "config": {"workload": "%s %dx%d, %d agents, %d envs per GPU, uniform random actions, reset every %d steps"
                                    % (args.game, eng.H, eng.W, n_agents, E, HORIZON),
                        "envs_per_gpu": E, "agents": n_agents, "obs": ("float32" if args.obs_f32 else "uint8") + " [E,N,15,15,3]", "launches_per_step": chains, "enqueue": ("ssd_rollout_random, %d chain(s) of %d envs" % (chains, E // chains)) if use_rollout else "one call per step",
-                       "gather": ("one RCCL all-gather of obs and one of rewards per %d steps, overlapped with the next %d steps" % (GR, GR)) if do_gather else False, "parallelism": "env-shard x%d" % world},
+                       "gather": ("one RCCL all-gather of obs and one of rewards per %d steps, overlapped with the next %d steps" % (GR, GR)) if do_gather else False, "parallelism": "env-shard x%d" % world,
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "ssd::ssd_env_kernel<%d, 0, %s, ...>" % (game, "true" if args.obs_f32 else "false"), "bytes_per_env_step": bytes_env,
-                         "avg_launch_us": launch_us, "concurrent_launches": chains, "envs_per_launch": E // chains,
+                         "clock": "wall time of the K timed steps (the same clock as value and ms_per_step)",
+                         "hip_event_us_per_step": dev_ms * 1e3 / args.steps, "concurrent_launches": chains, "envs_per_launch": E // chains,
                          "note": "achieved = algorithmic bytes per step (all concurrent launches) / time per step; each chain's launches "
                                  "run back to back on its own stream, so time per step = launch-to-launch duration of the step kernel", "host_enqueue_us_per_step": enq * 1e6 / args.steps},
         }
-        if fused_ms is not None:
-            fus = fused_ms * 1e3 / args.steps
+        if long_us is not None:
+            res["call_overhead_us"] = wall * 1e6 - args.steps * long_us
+            res["long_call_us_per_step"] = long_us
+        if fused_wall is not None:
+            fus = fused_wall * 1e6 / args.steps
             res["fused_rollout"] = {
                 "label": "NOT the headline: the same %d steps as ONE kernel launch per GPU (ssd_rollout_random + SSD_ROLLOUT_FUSED), "
                          "envs resident in LDS across steps; per-step obs / rew / done still written to HBM" % args.steps,
-                "value": total_agent_steps / (fused_ms * 1e-3), "unit": "agent-env-steps/s", "us_per_step": fus,
+                "value": total_agent_steps / fused_wall, "unit": "agent-env-steps/s", "us_per_step": fus,
                 "roofline_frac": bytes_env * E / (fus * 1e-6) / 1e9 / HBM_PEAK_GBS}
-        # HBM bytes per launch from the PMC counters of the committed profile of this exact workload
+            if fused_long_us is not None:
+                res["fused_rollout"]["long_call_us_per_step"] = fused_long_us
+        # HBM bytes per step from the PMC counters of the committed profile of this exact workload
         # (tools/profile_gpu.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE correction)
-        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
-        tkey = {"harvest": "harvest_16x38_n5_e4096", "cleanup": "cleanup_25x18_n5_e4096"}.get(args.game)
-        if tkey and E == 4096 and args.agents is None and not args.obs_f32 and os.path.exists(tpath):
-            res["roofline"]["traffic"] = json.load(open(tpath))[tkey]["hbm_bytes_per_launch"]
-            res["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 PMC, same workload)"
-            # and what rocprofv3 --kernel-trace --stats says one launch of that kernel lasts (committed summary; tracing slows
-            # the dispatch path down, so this is the kernel's duration in that regime, not the unprofiled step time)
-            spath = os.path.join(REPO, "profiles", "r01_final_kernel_stats.csv" if args.game == "harvest" else "r01_final_cleanup_kernel_stats.csv")
-            if os.path.exists(spath):
-                import csv
-                for row in csv.DictReader(open(spath)):
-                    if "ssd_env_kernel<%d, 0, false, 5, true, 1>" % (0 if args.game == "harvest" else 1) in row["Name"]:
-                        res["roofline"]["rocprof_avg_kernel_us"] = float(row["AverageNs"]) / 1e3
-                        res["roofline"]["rocprof_source"] = ("profiles/%s: per launch of %d envs under rocprofv3 --kernel-trace (which "
-                                                             "adds per-dispatch overhead: the same run's steps take 11.9 us there)" % (
-                                                                 os.path.basename(spath), E // chains))
+        tkey = "%s_%dx%d_n%d_e%d%s" % (args.game.rstrip("0123456789x"), eng.H, eng.W, n_agents, E, "_f32" if args.obs_f32 else "")
+        for rnd in (ROUND, "r01"):
+            tpath = os.path.join(REPO, "profiles", "%s_traffic.json" % rnd)
+            if not os.path.exists(tpath):
+                continue
+            ent = json.load(open(tpath)).get(tkey)
+            if ent and not args.pipelined:
+                res["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
+                res["roofline"]["traffic_source"] = "profiles/%s_traffic.json[%s] (rocprofv3 PMC, same workload; sum over the step's concurrent launches)" % (rnd, tkey)
+                if "rocprof_avg_kernel_us" in ent:
+                    # what rocprofv3 --kernel-trace --stats says one launch of that kernel lasts (committed summary; tracing slows
+                    # the dispatch path down, so this is the kernel's duration in that regime, not the unprofiled step time)
+                    res["roofline"]["rocprof_avg_kernel_us"] = ent["rocprof_avg_kernel_us"]
+                    res["roofline"]["rocprof_source"] = ent.get("rocprof_source")
+                break
+        if world == 1 and not args.no_configs:
+            # BASELINE.json's other single-GPU workloads (SURVEY.md 8d "state both": the 25x38 label; configs[2]; configs[4]'s
+            # per-GPU share), the float32-observation mode and the pipelined launches, a few hundred steps each
+            eng.close()
+            legs = [("cleanup", 4096, {}), ("harvest25x38", 4096, {}), ("cleanup48x36", 2048, {}),
+                    ("harvest", 4096, {"obs_f32": True}), ("harvest", 2048, {"pipelined": True, "ring_slots": 2})]
+            res["configs"] = [config_leg(torch, name, e, **kw) for name, e, kw in legs]
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(game, amap, n_agents)
         print(json.dumps(res), file=real_stdout)

@@ -1,0 +1,409 @@
+// csrc/ssd_aql.hip -- the library's own dispatch path: AQL packets written straight into HSA queues it owns.
+//
+// Why.  A rollout at the named batch (4096 envs) is launch-bound: the step kernel runs ~4.5 us, hipLaunchKernel costs
+// 2.3-3 us of host time per launch behind a runtime lock (two launches per step), and a short ssd_rollout_random call
+// (rollout.py:58-70 called per training iteration) paid ~50-100 us of runtime bookkeeping on top.  An AQL kernel-dispatch
+// packet is 64 bytes; writing one and ringing the doorbell takes ~0.1 us.  So ssd_rollout_random writes its step launches
+// itself:
+//   * one HSA user-mode queue per chain (env range), created once per handle;
+//   * the code object is the one hipcc built for the HIP path (the offload bundle of ssd_kernels.o, embedded a second time
+//     as plain data by ssd_codeobj.S), loaded through the HSA executable API; a kernel is looked up by the name HIP reports
+//     for the same __global__ stub (hipKernelNameRefByPtr), so both paths run the very same instantiation;
+//   * kernel arguments do not change from step to step (the state pointers, the output slot, the env range): they are
+//     written ONCE per (chain, ring slot, reset / step) into device memory and every packet of the rollout points at them --
+//     no per-launch argument traffic, and waves fetch their arguments from HBM, not from host memory;
+//   * ordering against the caller's HIP stream: FORK -- a one-wave HIP kernel on the stream zeroes an HSA signal that a
+//     barrier-AND packet at the head of every chain waits on; JOIN -- each chain ends with a one-wave dispatch (barrier bit)
+//     that bumps a counter in HIP signal memory, and the stream waits for it with hipStreamWaitValue64.
+// Packets within a chain carry the barrier bit and agent-scope acquire / release fences: the same ordering and visibility a
+// HIP stream gives consecutive kernels.
+//
+// Nothing here computes anything: if the HSA runtime, the queue or the code object cannot be set up, aql::available()
+// is false and ssd_rollout_random issues the same launches through hipLaunchKernel.  SSD_AQL=0 forces that.
+#include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <hsa/amd_hsa_signal.h>
+
+#include <dlfcn.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "ssd_internal.hpp"
+#include "ssd_aql.hpp"
+
+extern "C" const unsigned char ssd_kernels_bundle[];        // ssd_codeobj.S: the clang offload bundle of ssd_kernels.o
+extern "C" const unsigned char ssd_kernels_bundle_end[];
+
+namespace ssd {
+namespace aql {
+
+namespace {
+
+#define SSD_HSA_FUNCS(X)                                                                                                  \
+    X(hsa_init) X(hsa_iterate_agents) X(hsa_agent_get_info) X(hsa_amd_agent_iterate_memory_pools)                         \
+    X(hsa_amd_memory_pool_get_info) X(hsa_amd_memory_pool_allocate) X(hsa_amd_memory_pool_free)                           \
+    X(hsa_amd_agents_allow_access) X(hsa_queue_create) X(hsa_queue_destroy) X(hsa_queue_load_read_index_scacquire)         \
+    X(hsa_queue_store_write_index_screlease) X(hsa_signal_create) X(hsa_signal_destroy) X(hsa_signal_store_screlease)      \
+    X(hsa_signal_store_relaxed) X(hsa_signal_load_relaxed) X(hsa_code_object_reader_create_from_memory)                    \
+    X(hsa_code_object_reader_destroy) X(hsa_executable_create_alt) X(hsa_executable_load_agent_code_object)                \
+    X(hsa_executable_freeze) X(hsa_executable_get_symbol_by_name) X(hsa_executable_symbol_get_info) X(hsa_status_string)           \
+    X(hsa_amd_queue_set_priority)
+
+struct Api {
+#define X(f) decltype(&::f) f = nullptr;
+    SSD_HSA_FUNCS(X)
+#undef X
+};
+Api g_api;
+
+struct DeviceCtx {
+    bool tried = false, ok = false;
+    int device = -1;
+    hsa_agent_t gpu{}, cpu{};
+    hsa_amd_memory_pool_t host_kernarg_pool{};
+    hsa_executable_t exe{};
+    std::unordered_map<const void *, Kernel> kernels;     // by host stub
+    std::string why;                                      // why not ok
+};
+std::mutex g_mu;
+bool g_api_tried = false, g_api_ok = false;
+DeviceCtx g_dev[64];
+bool g_verbose = false;
+
+void say(const std::string &m) {
+    if (g_verbose) fprintf(stderr, "[ssd aql] %s\n", m.c_str());
+}
+
+bool load_api() {
+    if (g_api_tried) return g_api_ok;
+    g_api_tried = true;
+    { const char *v = getenv("SSD_AQL_VERBOSE"); g_verbose = v && atoi(v) != 0; }
+    // the HSA runtime the process already runs on (the HIP runtime's dependency): never a second copy
+    void *h = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("libhsa-runtime64.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) { say("HSA runtime not loaded in this process"); return false; }
+    bool all = true;
+#define X(f) g_api.f = reinterpret_cast<decltype(&::f)>(dlsym(h, #f)); if (!g_api.f) { all = false; say(std::string("missing ") + #f); }
+    SSD_HSA_FUNCS(X)
+#undef X
+    if (!all) return false;
+    if (g_api.hsa_init() != HSA_STATUS_SUCCESS) { say("hsa_init failed"); return false; }   // reference-counted: HIP holds one already
+    g_api_ok = true;
+    return true;
+}
+
+struct AgentSearch { uint32_t want_bdf, want_domain; bool found; hsa_agent_t gpu; bool have_cpu; hsa_agent_t cpu; };
+hsa_status_t agent_cb(hsa_agent_t a, void *data) {
+    auto *s = static_cast<AgentSearch *>(data);
+    hsa_device_type_t type;
+    if (g_api.hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &type) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    if (type == HSA_DEVICE_TYPE_CPU) { if (!s->have_cpu) { s->cpu = a; s->have_cpu = true; } return HSA_STATUS_SUCCESS; }
+    if (type != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+    uint32_t bdf = 0, domain = 0;
+    g_api.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
+    g_api.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
+    if (!s->found && bdf == s->want_bdf && domain == s->want_domain) { s->gpu = a; s->found = true; }
+    return HSA_STATUS_SUCCESS;
+}
+hsa_status_t pool_cb(hsa_amd_memory_pool_t pool, void *data) {
+    hsa_amd_segment_t seg;
+    if (g_api.hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg) != HSA_STATUS_SUCCESS || seg != HSA_AMD_SEGMENT_GLOBAL)
+        return HSA_STATUS_SUCCESS;
+    uint32_t flags = 0;
+    g_api.hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+    bool can_alloc = false;
+    g_api.hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &can_alloc);
+    if (can_alloc && (flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_KERNARG_INIT)) {
+        *static_cast<hsa_amd_memory_pool_t *>(data) = pool;
+        return HSA_STATUS_INFO_BREAK;
+    }
+    return HSA_STATUS_SUCCESS;
+}
+
+// the gfx950 code object inside the embedded clang offload bundle: magic, u64 count, then per entry u64 offset, u64 size,
+// u64 triple length, triple
+bool find_code_object(const unsigned char **co, size_t *size) {
+    const unsigned char *b = ssd_kernels_bundle;
+    const size_t n = (size_t)(ssd_kernels_bundle_end - ssd_kernels_bundle);
+    static const char magic[] = "__CLANG_OFFLOAD_BUNDLE__";
+    if (n < 32 || std::memcmp(b, magic, 24) != 0) return false;
+    uint64_t cnt;
+    std::memcpy(&cnt, b + 24, 8);
+    size_t pos = 32;
+    for (uint64_t i = 0; i < cnt; ++i) {
+        if (pos + 24 > n) return false;
+        uint64_t off, sz, tl;
+        std::memcpy(&off, b + pos, 8); std::memcpy(&sz, b + pos + 8, 8); std::memcpy(&tl, b + pos + 16, 8);
+        pos += 24;
+        if (pos + tl > n) return false;
+        const std::string triple(reinterpret_cast<const char *>(b + pos), (size_t)tl);
+        pos += tl;
+        if (triple.find("amdgcn-amd-amdhsa") != std::string::npos && triple.find("gfx950") != std::string::npos && off + sz <= n && sz > 0) {
+            *co = b + off; *size = (size_t)sz;
+            return true;
+        }
+    }
+    return false;
+}
+
+DeviceCtx *device_ctx(int device) {
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceCtx &c = g_dev[device];
+    if (c.tried) return c.ok ? &c : nullptr;
+    c.tried = true; c.device = device;
+    static const bool off = [] { const char *v = getenv("SSD_AQL"); return v && atoi(v) == 0; }();
+    if (off) { c.why = "SSD_AQL=0"; return nullptr; }
+    if (!load_api()) { c.why = "HSA runtime unavailable"; return nullptr; }
+    auto fail = [&](const std::string &m) -> DeviceCtx * { c.why = m; say(m); return nullptr; };
+    int can_wait = 0;
+    if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess || !can_wait)
+        return fail("device cannot hipStreamWaitValue");
+    // the HSA agent behind HIP device `device`: same PCI function
+    int dom = 0, bus = 0, dev = 0;
+    if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, device) != hipSuccess ||
+        hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, device) != hipSuccess ||
+        hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, device) != hipSuccess)
+        return fail("cannot read the device's PCI address");
+    AgentSearch s{};
+    s.want_domain = (uint32_t)dom;
+    for (uint32_t fn = 0; fn < 8 && !s.found; ++fn) {       // BDFID = bus << 8 | device << 3 | function
+        s.want_bdf = ((uint32_t)bus << 8) | ((uint32_t)dev << 3) | fn;
+        s.have_cpu = false;
+        g_api.hsa_iterate_agents(agent_cb, &s);
+    }
+    if (!s.found || !s.have_cpu) return fail("no HSA agent matches the HIP device's PCI address");
+    c.gpu = s.gpu; c.cpu = s.cpu;
+    c.host_kernarg_pool.handle = 0;
+    g_api.hsa_amd_agent_iterate_memory_pools(c.cpu, pool_cb, &c.host_kernarg_pool);
+    if (!c.host_kernarg_pool.handle) return fail("no kernarg memory pool");
+    const unsigned char *co = nullptr; size_t co_size = 0;
+    if (!find_code_object(&co, &co_size)) return fail("embedded code object not found");
+    hsa_code_object_reader_t reader;
+    hsa_status_t st = g_api.hsa_code_object_reader_create_from_memory(co, co_size, &reader);
+    if (st != HSA_STATUS_SUCCESS) return fail("code object reader failed");
+    st = g_api.hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &c.exe);
+    if (st != HSA_STATUS_SUCCESS) return fail("hsa_executable_create_alt failed");
+    st = g_api.hsa_executable_load_agent_code_object(c.exe, c.gpu, reader, nullptr, nullptr);
+    if (st != HSA_STATUS_SUCCESS) return fail("loading the code object failed");
+    st = g_api.hsa_executable_freeze(c.exe, nullptr);
+    if (st != HSA_STATUS_SUCCESS) return fail("hsa_executable_freeze failed");
+    c.ok = true;
+    say("device " + std::to_string(device) + ": own AQL dispatch path ready");
+    return &c;
+}
+
+}  // namespace
+
+bool available(int device) { return device_ctx(device) != nullptr; }
+
+const char *why_not(int device) {
+    if (device < 0 || device >= 64) return "bad device";
+    return g_dev[device].why.c_str();
+}
+
+bool lookup(int device, const void *host_fn, Kernel *out) {
+    DeviceCtx *c = device_ctx(device);
+    if (!c || !host_fn) return false;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = c->kernels.find(host_fn);
+    if (it != c->kernels.end()) { *out = it->second; return out->object != 0; }
+    Kernel k{};
+    const char *name = hipKernelNameRefByPtr(host_fn, nullptr);
+    if (name && *name) {
+        const std::string sym = std::string(name) + ".kd";
+        hsa_executable_symbol_t s;
+        if (g_api.hsa_executable_get_symbol_by_name(c->exe, sym.c_str(), &c->gpu, &s) == HSA_STATUS_SUCCESS) {
+            uint64_t obj = 0; uint32_t ka = 0, grp = 0, prv = 0;
+            g_api.hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &obj);
+            g_api.hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &ka);
+            g_api.hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &grp);
+            g_api.hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &prv);
+            k.object = obj; k.kernarg_size = ka; k.group_static = grp; k.private_size = prv;
+        } else {
+            say("kernel symbol not found: " + sym);
+        }
+    } else {
+        say("hipKernelNameRefByPtr gave no name");
+    }
+    c->kernels[host_fn] = k;
+    *out = k;
+    return k.object != 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+struct Queue {
+    DeviceCtx *ctx = nullptr;
+    hsa_queue_t *q = nullptr;
+    uint64_t widx = 0;                  // next packet index to write (this library is the queue's only producer)
+    uint64_t rung = 0;                  // packets below this index have been handed to the doorbell
+    uint32_t mask = 0;
+    std::atomic<int> error{0};
+    unsigned long long *join_flag = nullptr;    // HIP signal memory: the flag kernel's counter
+    uint64_t join_seq = 0;                      // value the counter reaches after the last join enqueued
+    void *flag_kernarg = nullptr;               // (host kernarg pool) the flag kernel's one argument
+    Kernel flag_kernel{};
+    hsa_signal_t done_signal{};                 // experiment (SSD_AQL_SIGNAL=1): completion signal attached to every dispatch
+};
+
+static void queue_error_cb(hsa_status_t status, hsa_queue_t *, void *data) {
+    auto *Q = static_cast<Queue *>(data);
+    Q->error.store((int)status ? (int)status : -1);
+    const char *msg = nullptr;
+    if (g_api.hsa_status_string) g_api.hsa_status_string(status, &msg);
+    fprintf(stderr, "[ssd aql] queue error: %s\n", msg ? msg : "?");
+}
+
+Queue *queue_create(int device) {
+    DeviceCtx *c = device_ctx(device);
+    if (!c) return nullptr;
+    static const int skip = [] { const char *v = getenv("SSD_AQL_SKIP_QUEUES"); return v ? atoi(v) : 0; }();   // experiment: spacer queues
+    for (int i = 0; i < skip; ++i) {
+        hsa_queue_t *dummy = nullptr;
+        g_api.hsa_queue_create(c->gpu, 64, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &dummy);   // (leaked on purpose)
+    }
+    Queue *Q = new Queue();
+    Q->ctx = c;
+    static const uint32_t qsize = [] { const char *v = getenv("SSD_AQL_QUEUE_SIZE"); int n = v ? atoi(v) : 4096; return (uint32_t)(n >= 64 ? n : 4096); }();
+    uint32_t size = 64;
+    while (size < qsize) size <<= 1;
+    static const int qtype = [] { const char *v = getenv("SSD_AQL_QUEUE_MULTI"); return v && atoi(v) ? (int)HSA_QUEUE_TYPE_MULTI : (int)HSA_QUEUE_TYPE_SINGLE; }();   // tuning
+    if (g_api.hsa_queue_create(c->gpu, size, (hsa_queue_type32_t)qtype, queue_error_cb, Q, UINT32_MAX, UINT32_MAX, &Q->q) != HSA_STATUS_SUCCESS) {
+        say("hsa_queue_create failed");
+        delete Q;
+        return nullptr;
+    }
+    static const int prio = [] { const char *v = getenv("SSD_AQL_PRIORITY"); return v ? atoi(v) : -1; }();   // tuning: 0 low 1 normal 2 high
+    if (prio >= 0) g_api.hsa_amd_queue_set_priority(Q->q, (hsa_amd_queue_priority_t)prio);
+    static const bool with_signal = [] { const char *v = getenv("SSD_AQL_SIGNAL"); return v && atoi(v) != 0; }();
+    if (with_signal) g_api.hsa_signal_create(1ll << 60, 0, nullptr, &Q->done_signal);
+    Q->mask = Q->q->size - 1;
+    Q->widx = Q->rung = g_api.hsa_queue_load_read_index_scacquire(Q->q);
+    void *flag = nullptr;
+    if (hipExtMallocWithFlags(&flag, 8, hipMallocSignalMemory) != hipSuccess || !flag) {
+        (void)hipGetLastError();
+        say("hipExtMallocWithFlags(hipMallocSignalMemory) failed");
+        g_api.hsa_queue_destroy(Q->q);
+        delete Q;
+        return nullptr;
+    }
+    Q->join_flag = static_cast<unsigned long long *>(flag);
+    if (hipStreamWriteValue64(nullptr, Q->join_flag, 0, 0) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+        (void)hipGetLastError();
+        say("hipStreamWriteValue64 failed");
+        queue_destroy(Q);
+        return nullptr;
+    }
+    bool ok = lookup(device, flag_kernel_fn(), &Q->flag_kernel);
+    if (ok) ok = g_api.hsa_amd_memory_pool_allocate(c->host_kernarg_pool, 64, 0, &Q->flag_kernarg) == HSA_STATUS_SUCCESS &&
+                 g_api.hsa_amd_agents_allow_access(1, &c->gpu, nullptr, Q->flag_kernarg) == HSA_STATUS_SUCCESS;
+    if (!ok) {
+        say("flag kernel setup failed");
+        queue_destroy(Q);
+        return nullptr;
+    }
+    std::memset(Q->flag_kernarg, 0, 64);
+    std::memcpy(Q->flag_kernarg, &Q->join_flag, sizeof(void *));
+    return Q;
+}
+
+void queue_destroy(Queue *Q) {
+    if (!Q) return;
+    if (Q->q) g_api.hsa_queue_destroy(Q->q);
+    if (Q->join_flag) (void)hipFree(Q->join_flag);
+    if (Q->flag_kernarg) g_api.hsa_amd_memory_pool_free(Q->flag_kernarg);
+    delete Q;
+}
+
+bool queue_failed(const Queue *Q) { return Q->error.load() != 0; }
+
+// Slot for the next packet.  Packets of a chain carry the barrier bit, so "packet j + 1 has been consumed" implies "packet j
+// has completed"; waiting until fewer than size - 2 packets are outstanding keeps a slot's previous occupant finished.
+static inline void *next_slot(Queue *Q) {
+    const uint64_t idx = Q->widx;
+    if (idx - g_api.hsa_queue_load_read_index_scacquire(Q->q) >= (uint64_t)Q->mask - 1) {
+        ring(Q);                                        // (the consumer must see what we have written before we wait for it)
+        while (idx - g_api.hsa_queue_load_read_index_scacquire(Q->q) >= (uint64_t)Q->mask - 1 && !Q->error.load())
+            __builtin_ia32_pause();
+    }
+    return static_cast<uint8_t *>(Q->q->base_address) + (idx & Q->mask) * 64;
+}
+
+static inline void publish(void *pk, uint16_t header, uint16_t setup) {
+    __atomic_store_n(static_cast<uint32_t *>(pk), (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
+}
+
+constexpr uint16_t header_of(int type, bool barrier, int acquire, int release) {
+    return (uint16_t)((type << HSA_PACKET_HEADER_TYPE) | ((barrier ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
+                      (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (release << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+}
+
+void dispatch(Queue *Q, const Kernel &k, uint32_t grid_x, uint32_t block_x, uint32_t lds_dynamic, const void *kernarg_dev,
+              bool barrier, int acquire_scope, int release_scope) {
+    auto *pk = static_cast<hsa_kernel_dispatch_packet_t *>(next_slot(Q));
+    pk->workgroup_size_x = (uint16_t)block_x; pk->workgroup_size_y = 1; pk->workgroup_size_z = 1; pk->reserved0 = 0;
+    pk->grid_size_x = grid_x * block_x; pk->grid_size_y = 1; pk->grid_size_z = 1;
+    pk->private_segment_size = k.private_size;
+    pk->group_segment_size = k.group_static + lds_dynamic;
+    pk->kernel_object = k.object;
+    pk->kernarg_address = const_cast<void *>(kernarg_dev);
+    pk->reserved2 = 0;
+    pk->completion_signal.handle = Q->done_signal.handle;
+    publish(pk, header_of(HSA_PACKET_TYPE_KERNEL_DISPATCH, barrier, acquire_scope, release_scope), 1 /* dimensions */);
+    Q->widx++;
+}
+
+void barrier_and(Queue *Q, uint64_t dep_signal_handle) {
+    auto *pk = static_cast<hsa_barrier_and_packet_t *>(next_slot(Q));
+    std::memset(reinterpret_cast<uint8_t *>(pk) + 4, 0, 60);
+    pk->dep_signal[0].handle = dep_signal_handle;
+    publish(pk, header_of(HSA_PACKET_TYPE_BARRIER_AND, true, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE), 0);
+    Q->widx++;
+}
+
+void ring(Queue *Q) {
+    if (Q->rung == Q->widx) return;
+    g_api.hsa_queue_store_write_index_screlease(Q->q, Q->widx);
+    g_api.hsa_signal_store_screlease(Q->q->doorbell_signal, (hsa_signal_value_t)(Q->widx - 1));
+    Q->rung = Q->widx;
+}
+
+uint64_t write_index(const Queue *Q) { return Q->widx; }
+uint64_t read_index(const Queue *Q) { return g_api.hsa_queue_load_read_index_scacquire(Q->q); }
+
+// JOIN: after everything enqueued so far on Q, bump the queue's counter (system-scope release), and make `stream` wait for it.
+bool join(Queue *Q, void *stream) {
+    dispatch(Q, Q->flag_kernel, 1, 64, 0, Q->flag_kernarg, /*barrier=*/true, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM);
+    ring(Q);
+    Q->join_seq++;
+    return hipStreamWaitValue64(static_cast<hipStream_t>(stream), Q->join_flag, Q->join_seq, hipStreamWaitValueGte, ~0ull) == hipSuccess;
+}
+
+// FORK signals
+uint64_t signal_create(long long initial) {
+    hsa_signal_t s{};
+    if (!g_api_ok || g_api.hsa_signal_create(initial, 0, nullptr, &s) != HSA_STATUS_SUCCESS) return 0;
+    return s.handle;
+}
+void signal_destroy(uint64_t h) {
+    if (h && g_api_ok) { hsa_signal_t s; s.handle = h; g_api.hsa_signal_destroy(s); }
+}
+void signal_set(uint64_t h, long long v) {
+    hsa_signal_t s; s.handle = h;
+    g_api.hsa_signal_store_screlease(s, v);
+}
+long long *signal_value_ptr(uint64_t h) {
+    // an hsa_signal_t handle is the address of its amd_signal_t; the value word is what packets and shaders poll / write
+    return reinterpret_cast<long long *>(const_cast<int64_t *>(&reinterpret_cast<amd_signal_t *>(h)->value));
+}
+
+}  // namespace aql
+}  // namespace ssd

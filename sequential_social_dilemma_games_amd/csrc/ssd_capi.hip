@@ -8,6 +8,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -15,10 +19,74 @@
 
 #include "../../include/ssd.h"
 #include "ssd_internal.hpp"
+#ifndef SSD_STAMPS
+#include "ssd_aql.hpp"
+#endif
 
 using ssd::Params;
 
 static thread_local std::string g_create_error;
+
+// One persistent host thread per extra rollout chain (ssd_rollout_random).  Created on the first multi-chain call, bound
+// to the handle's device once, then parked: a job is handed over through `state` (0 idle, 1 posted, 2 finished, 3 quit).
+// After a job the thread keeps polling for the next one for a short while before it sleeps on the condition variable, so a
+// loop of short rollout calls (rollout.py:58-70 called per training iteration) pays neither a thread creation + per-thread
+// HIP initialisation (~250 us per call: round 1) nor a futex wake-up per call.
+struct ChainJob {
+    bool pipelined = false;
+    int chain = 0, e_begin = 0, e_end = 0;
+    int32_t num_actions = 0, n_steps = 0, reset_every = 0, step0 = 0, ring = 1;
+    uint8_t *obs = nullptr; int32_t *rew = nullptr; uint8_t *done = nullptr;
+    uint32_t flags = 0;
+    hipStream_t s = nullptr;
+};
+struct ChainWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<int> state{0};
+    ChainJob job;
+    int rc = 0;
+};
+
+// ssd_rollout_random's own dispatch path (ssd_aql.hip): one HSA queue per chain; per (chain, ring slot) the kernel arguments of
+// the step launch and of the reset launch, written once into device memory and reused by every packet ("sets", keyed by what
+// the caller passed); a small ring of HSA signals for the fork from the caller's stream.
+#ifndef SSD_STAMPS
+struct AqlState {
+    bool tried = false, ok = false;
+    ssd::aql::Queue *q[8] = {};
+    int nq = 0;
+    static constexpr int kForks = 16;
+    uint64_t fork_sig[kForks] = {};
+    uint64_t fork_used[kForks][8] = {};             // index of the barrier packet that waits on the signal, per chain (+1; 0 = unused)
+    int fork_next = 0;
+    struct Key {
+        const void *obs = nullptr, *rew = nullptr, *done = nullptr;
+        int32_t ring = 0, f32 = 0, num_actions = 0, chains = 0, horizon = 0, coherent = 0;
+        bool operator==(const Key &o) const {
+            return obs == o.obs && rew == o.rew && done == o.done && ring == o.ring && f32 == o.f32 && num_actions == o.num_actions &&
+                   chains == o.chains && horizon == o.horizon && coherent == o.coherent;
+        }
+    };
+    struct Geo { ssd::aql::Kernel k; uint32_t grid_x = 0, block_x = 0, lds = 0; };
+    struct Set {
+        bool valid = false;
+        Key key;
+        uint8_t *dev = nullptr;                     // [chains][ring][3] blocks of kBlock bytes: step, reset, step with the other geometry
+        size_t cap = 0;
+        Geo step[8], reset[8], alt[8];              // per chain (alt: test knob SSD_AQL_ALTERNATE)
+        uint64_t last_use[8] = {};                  // index of the last join packet after a use, per chain (+1)
+        uint64_t stamp = 0;
+    };
+    static constexpr int kSets = 4;
+    static constexpr size_t kBlock = 512;           // >= sizeof(ssd::KernArgs), a multiple of 64
+    Set sets[kSets];
+    uint64_t clock = 0;
+};
+#else
+struct AqlState {};
+#endif
 
 struct ssd_env {
     int game = 0, H = 0, W = 0, WP = 0, S = 0, E = 0, N = 0, view_len = 7, V = 15, beam_len = 5;
@@ -48,6 +116,8 @@ struct ssd_env {
     ChainPipe chain_pipe[8];
     int wave_slots = 0;               // resident waves the device can hold (CUs x 32)
     int rollout_chains = 0;           // 0 = automatic
+    std::vector<std::unique_ptr<ChainWorker>> workers;   // workers[c - 1] enqueues chain c
+    std::unique_ptr<AqlState> aql;                       // the library's own dispatch path (ssd_aql.hip), set up on first use
     std::string err;
 };
 
@@ -390,10 +460,15 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
     return SSD_OK;
 }
 
+static void stop_workers(ssd_env *env);
+static void aql_teardown(ssd_env *env);
+
 int ssd_destroy(ssd_env *env) {
     if (!env) return SSD_E_INVALID;
+    stop_workers(env);
     (void)hipSetDevice(env->device);
     (void)hipDeviceSynchronize();
+    aql_teardown(env);
     for (void *ptr : env->allocs) (void)hipFree(ptr);
     for (void *ptr : env->host_allocs) (void)hipHostFree(ptr);
     for (hipStream_t cs : env->chain_streams) (void)hipStreamDestroy(cs);
@@ -439,8 +514,7 @@ int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, voi
                rew, done, 1, flags, stream);
 }
 
-// One chain of a rollout: the launches of steps [0, n_steps) for envs [e_begin, e_end), enqueued on `s`.
-// (main thread, before the chains' threads start) what chain c needs to pipeline its launches
+// (calling thread, before the chains' launches start) what chain c needs to pipeline its launches
 static int ensure_chain_pipe(ssd_env *env, int c) {
     if (!env->pipe_flags) { int rc = dev_alloc(env, &env->pipe_flags, (size_t)env->E); if (rc) return rc; }
     if (!env->wave_slots) {
@@ -456,28 +530,65 @@ static int ensure_chain_pipe(ssd_env *env, int c) {
     return SSD_OK;
 }
 
-static int rollout_chain(ssd_env *env, int chain, bool pipelined, int e_begin, int e_end, int32_t num_actions, int32_t n_steps, int32_t reset_every,
-                         int32_t step0, uint8_t *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, hipStream_t s) {
-    if (hipSetDevice(env->device) != hipSuccess) return SSD_E_DEVICE;
-    const bool f32 = (flags & SSD_OBS_F32) != 0;
-    const size_t en = (size_t)env->E * env->N, ob = obs_bytes(env, f32);
-    Params p = env->p;
-    p.obs_f32 = f32 ? 1 : 0;
-    p.e_begin = e_begin; p.E = e_end;
-    if (flags & SSD_ROLLOUT_FUSED) {
+// The launches of step k of a plain (neither fused nor pipelined) chain: a full reset when one is due, then the step.
+struct ChainCursor {
+    Params p;
+    hipStream_t s;
+    uint8_t *obs; int32_t *rew; uint8_t *done;
+    size_t en, ob;
+    int32_t num_actions, reset_every, step0, ring;
+};
+static ChainCursor chain_cursor(const ssd_env *env, const ChainJob &j) {
+    ChainCursor c;
+    const bool f32 = (j.flags & SSD_OBS_F32) != 0;
+    c.p = env->p;
+    c.p.obs_f32 = f32 ? 1 : 0;
+    c.p.e_begin = j.e_begin; c.p.E = j.e_end;
+    c.s = j.s; c.obs = j.obs; c.rew = j.rew; c.done = j.done;
+    c.en = (size_t)env->E * env->N; c.ob = obs_bytes(env, f32);
+    c.num_actions = j.num_actions; c.reset_every = j.reset_every; c.step0 = j.step0; c.ring = j.ring;
+    return c;
+}
+static inline void chain_launch_step(const ssd_env *env, ChainCursor &c, int k) {
+    Params &p = c.p;
+    const size_t slot = (size_t)((c.step0 + k) % c.ring);
+    p.obs = c.obs ? c.obs + slot * c.ob : nullptr;
+    if (c.reset_every > 0 && (c.step0 + k) % c.reset_every == 0) {
+        p.mode = ssd::kModeReset; p.rotate = 0; p.num_actions_random = 0; p.rew = nullptr; p.done = nullptr;
+        ssd::launch(p, env->game, c.s);
+    }
+    p.mode = ssd::kModeStep; p.rotate = 1; p.num_actions_random = c.num_actions;
+    p.rew = c.rew ? c.rew + slot * c.en : nullptr; p.done = c.done ? c.done + slot * c.en : nullptr;
+    ssd::launch(p, env->game, c.s);
+}
+
+// One chain of a rollout: the launches of steps [0, n_steps) for envs [e_begin, e_end), enqueued on j.s by the calling thread
+// (which is on the handle's device).
+static int rollout_chain(ssd_env *env, const ChainJob &j) {
+    const int32_t n_steps = j.n_steps, reset_every = j.reset_every, step0 = j.step0, ring = j.ring;
+    hipStream_t s = j.s;
+    if (j.flags & SSD_ROLLOUT_FUSED) {
         // ONE launch for the whole chain: the kernel keeps each env in LDS / registers across its n_steps steps
         if (n_steps == 0) return SSD_OK;
-        p.mode = ssd::kModeRollout; p.rotate = 1; p.num_actions_random = num_actions;
+        Params p = env->p;
+        p.obs_f32 = 0;
+        p.e_begin = j.e_begin; p.E = j.e_end;
+        p.mode = ssd::kModeRollout; p.rotate = 1; p.num_actions_random = j.num_actions;
         p.n_steps = n_steps; p.reset_every = reset_every; p.step0 = step0; p.ring = ring;
-        p.obs = obs; p.rew = rew; p.done = done;
+        p.obs = j.obs; p.rew = j.rew; p.done = j.done;
         ssd::launch(p, env->game, s);
         return hipGetLastError() == hipSuccess ? SSD_OK : SSD_E_DEVICE;
     }
-    if (pipelined) {
+    if (j.pipelined) {
         // Step launches alternate between the chain's stream and a second one, so two consecutive steps may be in flight at
         // once; what orders them is the per-env pass counter the kernels wait on and publish (kernel: PIPE).  A reset launch
         // joins the two streams, runs alone, and the counters start again from zero.
-        auto &cp = env->chain_pipe[chain];
+        const bool f32 = (j.flags & SSD_OBS_F32) != 0;
+        const size_t en = (size_t)env->E * env->N, ob = obs_bytes(env, f32);
+        Params p = env->p;
+        p.obs_f32 = f32 ? 1 : 0;
+        p.e_begin = j.e_begin; p.E = j.e_end;
+        auto &cp = env->chain_pipe[j.chain];
         hipStream_t st[2] = {s, cp.sb};
         uint32_t seq = 0;
         // test knob: the first launch of the call waits for a pass that never ran -- its waves must give up (bounded wait), set
@@ -487,14 +598,14 @@ static int rollout_chain(ssd_env *env, int chain, bool pipelined, int e_begin, i
         auto restart = [&]() -> bool {
             seq = stall_once ? 1 : 0;
             stall_once = false;
-            return hipMemsetAsync(env->pipe_flags + e_begin, 0, sizeof(uint32_t) * (size_t)(e_end - e_begin), s) == hipSuccess &&
+            return hipMemsetAsync(env->pipe_flags + j.e_begin, 0, sizeof(uint32_t) * (size_t)(j.e_end - j.e_begin), s) == hipSuccess &&
                    hipEventRecord(cp.ev_a, s) == hipSuccess && hipStreamWaitEvent(cp.sb, cp.ev_a, 0) == hipSuccess;
         };
         auto join = [&]() -> bool { return hipEventRecord(cp.ev_b, cp.sb) == hipSuccess && hipStreamWaitEvent(s, cp.ev_b, 0) == hipSuccess; };
         if (!restart()) return SSD_E_DEVICE;
         for (int k = 0; k < n_steps; ++k) {
             const size_t slot = (size_t)((step0 + k) % ring);
-            p.obs = obs ? obs + slot * ob : nullptr;
+            p.obs = j.obs ? j.obs + slot * ob : nullptr;
             if (reset_every > 0 && (step0 + k) % reset_every == 0) {
                 if (!join()) return SSD_E_DEVICE;
                 p.mode = ssd::kModeReset; p.rotate = 0; p.num_actions_random = 0; p.rew = nullptr; p.done = nullptr;
@@ -502,8 +613,8 @@ static int rollout_chain(ssd_env *env, int chain, bool pipelined, int e_begin, i
                 ssd::launch(p, env->game, s);
                 if (!restart()) return SSD_E_DEVICE;
             }
-            p.mode = ssd::kModeStep; p.rotate = 1; p.num_actions_random = num_actions;
-            p.rew = rew ? rew + slot * en : nullptr; p.done = done ? done + slot * en : nullptr;
+            p.mode = ssd::kModeStep; p.rotate = 1; p.num_actions_random = j.num_actions;
+            p.rew = j.rew ? j.rew + slot * en : nullptr; p.done = j.done ? j.done + slot * en : nullptr;
             static const uint32_t rotate = [] { const char *v = getenv("SSD_PIPE_ROTATE"); return v ? (uint32_t)atoi(v) : 0u; }();   // test knob
             p.pipe_flags = env->pipe_flags; p.pipe_seq = ++seq; p.pipe_rotate = rotate;
             ssd::launch(p, env->game, st[(seq - 1) & 1]);
@@ -511,19 +622,228 @@ static int rollout_chain(ssd_env *env, int chain, bool pipelined, int e_begin, i
         if (!join()) return SSD_E_DEVICE;
         return hipGetLastError() == hipSuccess ? SSD_OK : SSD_E_DEVICE;
     }
-    for (int k = 0; k < n_steps; ++k) {
-        const size_t slot = (size_t)((step0 + k) % ring);
-        p.obs = obs ? obs + slot * ob : nullptr;
-        if (reset_every > 0 && (step0 + k) % reset_every == 0) {
-            p.mode = ssd::kModeReset; p.rotate = 0; p.num_actions_random = 0; p.rew = nullptr; p.done = nullptr;
-            ssd::launch(p, env->game, s);
-        }
-        p.mode = ssd::kModeStep; p.rotate = 1; p.num_actions_random = num_actions;
-        p.rew = rew ? rew + slot * en : nullptr; p.done = done ? done + slot * en : nullptr;
-        ssd::launch(p, env->game, s);
-    }
+    ChainCursor c = chain_cursor(env, j);
+    for (int k = 0; k < n_steps; ++k) chain_launch_step(env, c, k);
     return hipGetLastError() == hipSuccess ? SSD_OK : SSD_E_DEVICE;
 }
+
+// Body of a chain worker thread (see ChainWorker).
+static void chain_worker_main(ssd_env *env, ChainWorker *w) {
+    const bool on_device = hipSetDevice(env->device) == hipSuccess;       // once per thread
+    static const int spin_us = [] { const char *v = getenv("SSD_WORKER_SPIN_US"); return v ? atoi(v) : 200; }();
+    for (;;) {
+        int st = w->state.load(std::memory_order_acquire);
+        if (st != 1 && st != 3) {
+            // poll for a while (the caller of a rollout loop is back within microseconds), then sleep
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                st = w->state.load(std::memory_order_acquire);
+                if (st == 1 || st == 3) break;
+                __builtin_ia32_pause();
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+            }
+            if (st != 1 && st != 3) {
+                std::unique_lock<std::mutex> lk(w->mu);
+                w->cv.wait(lk, [&] { const int v = w->state.load(std::memory_order_acquire); return v == 1 || v == 3; });
+                st = w->state.load(std::memory_order_acquire);
+            }
+        }
+        if (st == 3) return;
+        w->rc = on_device ? rollout_chain(env, w->job) : SSD_E_DEVICE;
+        w->state.store(2, std::memory_order_release);
+    }
+}
+static void post_job(ChainWorker *w, const ChainJob &j) {
+    w->job = j;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->state.store(1, std::memory_order_release);
+    }
+    w->cv.notify_one();
+}
+static int wait_job(ChainWorker *w) {
+    // the worker finishes within microseconds of the caller's own chain: poll
+    for (int spins = 0; w->state.load(std::memory_order_acquire) != 2; ++spins) {
+        if (spins < 4096) __builtin_ia32_pause();
+        else std::this_thread::yield();
+    }
+    w->state.store(0, std::memory_order_relaxed);
+    return w->rc;
+}
+static void stop_workers(ssd_env *env) {
+    for (auto &w : env->workers) {
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->state.store(3, std::memory_order_release);
+        }
+        w->cv.notify_one();
+        if (w->th.joinable()) w->th.join();
+    }
+    env->workers.clear();
+}
+
+#ifndef SSD_STAMPS
+static void aql_teardown(ssd_env *env) {
+    if (!env->aql) return;
+    AqlState &A = *env->aql;
+    for (int c = 0; c < 8; ++c) if (A.q[c]) ssd::aql::queue_destroy(A.q[c]);
+    for (uint64_t h : A.fork_sig) ssd::aql::signal_destroy(h);
+    for (auto &st : A.sets) if (st.dev) (void)hipFree(st.dev);
+    env->aql.reset();
+}
+
+// Queues for `chains` chains, fork signals: created once.  false: use hipLaunchKernel.
+static bool aql_ready(ssd_env *env, int chains) {
+    if (!env->aql) env->aql.reset(new AqlState());
+    AqlState &A = *env->aql;
+    if (A.tried && !A.ok) return false;
+    if (!A.tried) {
+        A.tried = true;
+        if (!ssd::aql::available(env->device)) return false;
+        for (int i = 0; i < AqlState::kForks; ++i) {
+            A.fork_sig[i] = ssd::aql::signal_create(0);
+            if (!A.fork_sig[i]) return false;
+        }
+        A.ok = true;
+    }
+    while (A.nq < chains) {
+        A.q[A.nq] = ssd::aql::queue_create(env->device);
+        if (!A.q[A.nq]) { A.ok = false; return false; }
+        A.nq++;
+    }
+    for (int c = 0; c < A.nq; ++c) if (ssd::aql::queue_failed(A.q[c])) { A.ok = false; return false; }
+    return true;
+}
+
+static inline void aql_wait_consumed(ssd::aql::Queue *q, uint64_t idx_plus_1) {
+    // (bounded in practice: the packets in question belong to calls made long ago)
+    while (idx_plus_1 && ssd::aql::read_index(q) < idx_plus_1 && !ssd::aql::queue_failed(q)) __builtin_ia32_pause();
+}
+
+// The kernel-argument set for this call's parameters: found among the cached ones, or built, uploaded (synchronously) and cached.
+static AqlState::Set *aql_set(ssd_env *env, const AqlState::Key &key, int chains, const ChainJob *jobs) {
+    AqlState &A = *env->aql;
+    A.clock++;
+    for (auto &st : A.sets) if (st.valid && st.key == key) { st.stamp = A.clock; return &st; }
+    AqlState::Set *victim = &A.sets[0];
+    for (auto &st : A.sets) { if (!st.valid) { victim = &st; break; } if (st.stamp < victim->stamp) victim = &st; }
+    AqlState::Set &st = *victim;
+    if (st.valid) for (int c = 0; c < 8 && c < A.nq; ++c) aql_wait_consumed(A.q[c], st.last_use[c]);   // nobody reads the old blocks any more
+    st.valid = false;
+    const size_t need = (size_t)chains * key.ring * 3 * AqlState::kBlock;
+    if (need > st.cap) {
+        if (st.dev) (void)hipFree(st.dev);
+        st.dev = nullptr; st.cap = 0;
+        void *ptr = nullptr;
+        if (hipMalloc(&ptr, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        st.dev = static_cast<uint8_t *>(ptr); st.cap = need;
+    }
+    std::vector<uint8_t> host(need, 0);
+    for (int c = 0; c < chains; ++c) {
+        ChainCursor cur = chain_cursor(env, jobs[c]);
+        for (int r = 0; r < key.ring; ++r)
+            for (int kind = 0; kind < 3; ++kind) {
+                if (kind == 2 && key.coherent != 2) continue;
+                Params p = cur.p;
+                p.obs = cur.obs ? cur.obs + (size_t)r * cur.ob : nullptr;
+                p.coherent = key.coherent ? (kind == 2 ? 2u : 1u) : 0u;
+                if (kind == 1) { p.mode = ssd::kModeReset; p.rotate = 0; p.num_actions_random = 0; p.rew = nullptr; p.done = nullptr; }
+                else {
+                    p.mode = ssd::kModeStep; p.rotate = 1; p.num_actions_random = cur.num_actions;
+                    p.rew = cur.rew ? cur.rew + (size_t)r * cur.en : nullptr; p.done = cur.done ? cur.done + (size_t)r * cur.en : nullptr;
+                }
+                ssd::Launch L;
+                if (!ssd::select(p, env->game, &L)) return nullptr;
+                AqlState::Geo &g = kind == 1 ? st.reset[c] : kind == 2 ? st.alt[c] : st.step[c];
+                if (r == 0) {
+                    if (!ssd::aql::lookup(env->device, L.fn, &g.k) || g.k.kernarg_size > AqlState::kBlock || g.k.kernarg_size < sizeof(ssd::KernArgs)) return nullptr;
+                    g.grid_x = L.grid_x; g.block_x = L.block_x; g.lds = L.lds;
+                }
+                std::memcpy(host.data() + (((size_t)c * key.ring + r) * 3 + kind) * AqlState::kBlock, &L.args, sizeof(ssd::KernArgs));
+            }
+    }
+    if (hipMemcpy(st.dev, host.data(), need, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    st.key = key; st.valid = true; st.stamp = A.clock;
+    for (auto &u : st.last_use) u = 0;
+    return &st;
+}
+
+// ssd_rollout_random through the library's own queues.  Returns SSD_OK, an error, or 1 = "not taken" (the caller then issues
+// the same launches through hipLaunchKernel).
+static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream_t s) {
+    if (!aql_ready(env, chains)) return 1;
+    AqlState &A = *env->aql;
+    const ChainJob &j0 = jobs[0];
+    AqlState::Key key;
+    key.obs = j0.obs; key.rew = j0.rew; key.done = j0.done; key.ring = j0.ring; key.f32 = (j0.flags & SSD_OBS_F32) ? 1 : 0;
+    key.num_actions = j0.num_actions; key.chains = chains; key.horizon = env->p.horizon;
+    // Coherent chains: with a map-specific uint8 kernel (and its write-through observation stores: up to 16 384 envs per launch)
+    // state and outputs move with agent-scope accesses only, so the step packets need no release fence (ssd_kernels.hip, PIPE = 2).
+    // SSD_AQL_COHERENT=0 keeps the plain kernels with agent-scope acquire + release on every packet; SSD_AQL_ALTERNATE=1 (test)
+    // makes every other step launch use half the envs per workgroup -- an env then changes workgroup, and with it XCD and L2, from
+    // one step to the next.
+    static const int env_coh = [] { const char *v = getenv("SSD_AQL_COHERENT"); return v ? atoi(v) : 1; }();
+    static const bool alternate = [] { const char *v = getenv("SSD_AQL_ALTERNATE"); return v && atoi(v) != 0; }();
+    const bool coherent = env_coh != 0 && !key.f32 && ssd::fast_profile(env->p, env->game) > 0 && (env->E + chains - 1) / chains <= 16384;
+    key.coherent = coherent ? (alternate ? 2 : 1) : 0;
+    if ((size_t)chains * j0.ring > 4096) return 1;                     // (argument blocks: 2 x 512 B per chain and slot)
+    AqlState::Set *st = aql_set(env, key, chains, jobs);
+    if (!st) return 1;
+    if (j0.n_steps == 0) return SSD_OK;
+    // FORK: the chains wait (barrier-AND) for a signal that a one-wave kernel on the caller's stream zeroes -- unless the
+    // stream has nothing pending, in which case there is nothing to wait for and the first step can start at once
+    static const bool always_fork = [] { const char *v = getenv("SSD_AQL_ALWAYS_FORK"); return v && atoi(v) != 0; }();
+    const bool stream_idle = !always_fork && hipStreamQuery(s) == hipSuccess;
+    if (!stream_idle) {
+        (void)hipGetLastError();                                       // (hipErrorNotReady is not an error here)
+        const int slot = A.fork_next;
+        A.fork_next = (A.fork_next + 1) % AqlState::kForks;
+        for (int c = 0; c < A.nq; ++c) { aql_wait_consumed(A.q[c], A.fork_used[slot][c]); A.fork_used[slot][c] = 0; }
+        ssd::aql::signal_set(A.fork_sig[slot], 1);
+        ssd::launch_signal_kernel(ssd::aql::signal_value_ptr(A.fork_sig[slot]), s);
+        if (hipGetLastError() != hipSuccess) { env->err = "fork kernel launch failed"; return SSD_E_DEVICE; }
+        for (int c = 0; c < chains; ++c) {
+            ssd::aql::barrier_and(A.q[c], A.fork_sig[slot]);
+            A.fork_used[slot][c] = ssd::aql::write_index(A.q[c]);     // (= index of the barrier packet + 1)
+        }
+    }
+    // fence scopes of the step packets (hsa_fence_scope_t: 0 none, 1 agent, 2 system) and their barrier bit; the SSD_AQL_*
+    // variables are tuning knobs -- anything weaker than agent / agent / 1 gives up the ordering a HIP stream provides
+    static const int env_acq = [] { const char *v = getenv("SSD_AQL_ACQ"); return v ? atoi(v) : -1; }();
+    static const int env_rel = [] { const char *v = getenv("SSD_AQL_REL"); return v ? atoi(v) : -1; }();
+    const int kAcq = env_acq >= 0 ? env_acq : 1, kRel = env_rel >= 0 ? env_rel : (coherent ? 0 : 1);
+    static const bool kBar = [] { const char *v = getenv("SSD_AQL_BARRIER"); return v ? atoi(v) != 0 : true; }();
+    const int32_t ring = j0.ring, reset_every = j0.reset_every, step0 = j0.step0;
+    for (int k = 0; k < j0.n_steps; ++k) {
+        const size_t r = (size_t)((step0 + k) % ring);
+        const bool reset = reset_every > 0 && (step0 + k) % reset_every == 0;
+        for (int c = 0; c < chains; ++c) {
+            const uint8_t *blocks = st->dev + (((size_t)c * ring + r) * 3) * AqlState::kBlock;
+            if (reset) {
+                const AqlState::Geo &g = st->reset[c];
+                ssd::aql::dispatch(A.q[c], g.k, g.grid_x, g.block_x, g.lds, blocks + AqlState::kBlock, true, 1, kRel);
+            }
+            const bool other = key.coherent == 2 && ((step0 + k) & 1);
+            const AqlState::Geo &g = other ? st->alt[c] : st->step[c];
+            ssd::aql::dispatch(A.q[c], g.k, g.grid_x, g.block_x, g.lds, blocks + (other ? 2 * AqlState::kBlock : 0), kBar, kAcq, kRel);
+            ssd::aql::ring(A.q[c]);
+        }
+    }
+    // JOIN: the caller's stream continues after every chain
+    bool ok = true;
+    static const bool host_join = [] { const char *v = getenv("SSD_AQL_HOST_JOIN"); return v && atoi(v) != 0; }();   // experiment: no stream wait, the call blocks
+    for (int c = 0; c < chains; ++c) {
+        if (host_join) { ssd::aql::ring(A.q[c]); while (ssd::aql::read_index(A.q[c]) < ssd::aql::write_index(A.q[c])) __builtin_ia32_pause(); }
+        else ok = ssd::aql::join(A.q[c], s) && ok;
+        st->last_use[c] = ssd::aql::write_index(A.q[c]);
+    }
+    if (!ok) { (void)hipGetLastError(); env->err = "hipStreamWaitValue64 failed"; A.ok = false; return SSD_E_DEVICE; }
+    for (int c = 0; c < chains; ++c) if (ssd::aql::queue_failed(A.q[c])) { env->err = "the HSA runtime reported an error on a dispatch queue"; A.ok = false; return SSD_E_DEVICE; }
+    return SSD_OK;
+}
+#else
+static void aql_teardown(ssd_env *) {}
+#endif
 
 int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32_t reset_every, int32_t step0,
                        void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream) {
@@ -533,7 +853,10 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
     if (num_actions < 1 || num_actions > na) { env->err = "num_actions outside the game's Discrete(n)"; return SSD_E_INVALID; }
     if (obs && (reinterpret_cast<uintptr_t>(obs) & 3u)) { env->err = "obs must be 4-byte aligned"; return SSD_E_INVALID; }
     if ((flags & SSD_ROLLOUT_FUSED) && (flags & SSD_OBS_F32)) { env->err = "the fused rollout kernel writes uint8 observations"; return SSD_E_INVALID; }
-    SSD_HIP(env, hipSetDevice(env->device));
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != env->device) SSD_HIP(env, hipSetDevice(env->device));
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     uint8_t *o = static_cast<uint8_t *>(obs);
     // Pipelined launches (SSD_ROLLOUT_PIPELINED; SSD_ROLLOUT_PIPELINE=1 / 0 in the environment forces / forbids them): only the
@@ -557,12 +880,22 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
         static const bool tight = [] { const char *v = getenv("SSD_PIPELINE_TIGHT"); return v && atoi(v) != 0; }();   // tuning: no margin
         if (2LL * env->E * (tight ? 4 : 5) > cap * 4) pipelined = false;
     }
-    // Envs are independent, so a rollout is as many independent launch chains as we like.  Two chains on two streams
-    // (each enqueued by its own host thread) keep the GPU busy while the other chain's kernel drains and the next one is
-    // dispatched -- the ~2 us per launch that a single chain of 9 us kernels cannot hide.  SSD_ROLLOUT_CHAINS overrides.
+    // Envs are independent, so a rollout is as many independent launch chains as we like.  Two chains on two streams keep the
+    // GPU busy while the other chain's kernel drains and the next one is dispatched -- the ~2 us per launch that a single
+    // chain of dependent kernels cannot hide.  SSD_ROLLOUT_CHAINS overrides.
     static const int forced = [] { const char *v = getenv("SSD_ROLLOUT_CHAINS"); return v ? atoi(v) : 0; }();
-    int chains = env->rollout_chains > 0 ? env->rollout_chains : forced > 0 ? forced : (n_steps < 16 || env->E < 2048 ? 1 : (env->E >= 6144 && env->E <= 24576) ? 3 : 2);   // measured: profiles/r01_sweep_envs.txt
+    int chains = env->rollout_chains > 0 ? env->rollout_chains : forced > 0 ? forced : (env->E < 2048 ? 1 : (env->E >= 6144 && env->E <= 24576) ? 3 : 2);   // measured: profiles/r01_sweep_envs.txt
     if ((flags & SSD_ROLLOUT_FUSED) && env->rollout_chains <= 0 && forced <= 0) chains = 1;   // one launch already covers the whole rollout
+    // From here on every exit path must give the device's pipelining slot back: the guard does.
+    struct PipeGuard {
+        ssd_env *env; bool held = false; hipStream_t s;
+        ~PipeGuard() {
+            if (!held) return;
+            if (env->pipe_done) (void)hipEventRecord(env->pipe_done, s);
+            std::lock_guard<std::mutex> lk(g_pipe_owners.mu);
+            if (g_pipe_owners.enqueuing[env->device & 63] == env) g_pipe_owners.enqueuing[env->device & 63] = nullptr;
+        }
+    } guard{env, false, s};
     if (pipelined) {
         if (!env->pipe_done) SSD_HIP(env, hipEventCreateWithFlags(&env->pipe_done, hipEventDisableTiming));
         std::lock_guard<std::mutex> lk(g_pipe_owners.mu);
@@ -570,21 +903,36 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
         if ((g_pipe_owners.enqueuing[d] && g_pipe_owners.enqueuing[d] != env) ||
             (g_pipe_owners.owner[d] && g_pipe_owners.owner[d] != env && hipEventQuery(g_pipe_owners.done[d]) == hipErrorNotReady))
             pipelined = false;                                      // another handle's pipelined rollout is being enqueued or still in flight
-        else
+        else {
             g_pipe_owners.owner[d] = g_pipe_owners.enqueuing[d] = env, g_pipe_owners.done[d] = env->pipe_done;
+            guard.held = true;
+        }
     }
     if (pipelined && env->rollout_chains <= 0 && forced <= 0) chains = 1;   // a pipelined chain overlaps its own launches (measured: 1 beats 2)
     if (chains > 8) chains = 8;
     if (chains > env->E) chains = env->E;
+    if (chains < 1) chains = 1;
     for (int c = 1; pipelined && c < chains; ++c) { int rc = ensure_chain_pipe(env, c); if (rc) return rc; }
+    auto range = [&](int c) { return (int)(((long long)env->E * c) / chains); };
+    auto job_of = [&](int c, hipStream_t cs) {
+        ChainJob j;
+        j.pipelined = pipelined; j.chain = c; j.e_begin = range(c); j.e_end = range(c + 1);
+        j.num_actions = num_actions; j.n_steps = n_steps; j.reset_every = reset_every; j.step0 = step0; j.ring = ring;
+        j.obs = o; j.rew = rew; j.done = done; j.flags = flags; j.s = cs;
+        return j;
+    };
+#ifndef SSD_STAMPS
+    if (!pipelined && !(flags & SSD_ROLLOUT_FUSED)) {
+        // the library's own dispatch path: the same launches as below, written as AQL packets into its own queues
+        ChainJob jobs[8];
+        for (int c = 0; c < chains; ++c) jobs[c] = job_of(c, s);
+        const int rc = rollout_aql(env, chains, jobs, s);
+        if (rc <= 0) return rc;
+    }
+#endif
     if (chains <= 1) {
-        int rc = rollout_chain(env, 0, pipelined, 0, env->E, num_actions, n_steps, reset_every, step0, o, rew, done, ring, flags, s);
+        int rc = rollout_chain(env, job_of(0, s));
         if (rc) env->err = "kernel launch failed in ssd_rollout_random";
-        if (pipelined) {
-            (void)hipEventRecord(env->pipe_done, s);
-            std::lock_guard<std::mutex> lk(g_pipe_owners.mu);
-            g_pipe_owners.enqueuing[env->device & 63] = nullptr;
-        }
         return rc;
     }
     while ((int)env->chain_streams.size() < chains - 1) {
@@ -594,32 +942,44 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
         env->chain_streams.push_back(ns); env->chain_events.push_back(ne);
     }
     if (!env->fork_event) SSD_HIP(env, hipEventCreateWithFlags(&env->fork_event, hipEventDisableTiming));
+    // Who enqueues.  The chains' launches either come from this thread, step by step across the chains (no other thread
+    // involved: a short call costs its launches and nothing else), or each extra chain from its persistent worker thread
+    // (long calls: two threads enqueue ~10 % faster than one, and pipelined chains have per-chain state machines).
+    // SSD_ROLLOUT_THREADS=0 / 1 forces one or the other.
+    static const int env_threads = [] { const char *v = getenv("SSD_ROLLOUT_THREADS"); return v ? atoi(v) : -1; }();
+    static const int inline_steps = [] { const char *v = getenv("SSD_ROLLOUT_INLINE_STEPS"); return v ? atoi(v) : 256; }();
+    bool threads = pipelined || (!(flags & SSD_ROLLOUT_FUSED) && n_steps > inline_steps);
+    if (env_threads == 0 && !pipelined) threads = false;
+    if (env_threads == 1) threads = true;
     // fork: the extra chains start after whatever the caller's stream holds so far
     SSD_HIP(env, hipEventRecord(env->fork_event, s));
     for (int c = 1; c < chains; ++c) SSD_HIP(env, hipStreamWaitEvent(env->chain_streams[c - 1], env->fork_event, 0));
-    std::vector<int> rcs(chains, SSD_OK);
-    std::vector<std::thread> workers;
-    auto range = [&](int c) { return (int)(((long long)env->E * c) / chains); };
-    for (int c = 1; c < chains; ++c)
-        workers.emplace_back([&, c] {
-            rcs[c] = rollout_chain(env, c, pipelined, range(c), range(c + 1), num_actions, n_steps, reset_every, step0, o, rew, done, ring, flags,
-                                   env->chain_streams[c - 1]);
-        });
-    rcs[0] = rollout_chain(env, 0, pipelined, range(0), range(1), num_actions, n_steps, reset_every, step0, o, rew, done, ring, flags, s);
-    for (auto &w : workers) w.join();
+    int rc_all = SSD_OK;
+    if (threads) {
+        while ((int)env->workers.size() < chains - 1) {
+            env->workers.emplace_back(new ChainWorker());
+            ChainWorker *w = env->workers.back().get();
+            w->th = std::thread(chain_worker_main, env, w);
+        }
+        for (int c = 1; c < chains; ++c) post_job(env->workers[c - 1].get(), job_of(c, env->chain_streams[c - 1]));
+        rc_all = rollout_chain(env, job_of(0, s));
+        for (int c = 1; c < chains; ++c) { const int rc = wait_job(env->workers[c - 1].get()); if (rc && !rc_all) rc_all = rc; }
+    } else if (flags & SSD_ROLLOUT_FUSED) {
+        for (int c = 0; c < chains; ++c) { const int rc = rollout_chain(env, job_of(c, c ? env->chain_streams[c - 1] : s)); if (rc && !rc_all) rc_all = rc; }
+    } else {
+        ChainCursor cur[8];
+        for (int c = 0; c < chains; ++c) cur[c] = chain_cursor(env, job_of(c, c ? env->chain_streams[c - 1] : s));
+        for (int k = 0; k < n_steps; ++k)
+            for (int c = 0; c < chains; ++c) chain_launch_step(env, cur[c], k);
+        if (hipGetLastError() != hipSuccess) rc_all = SSD_E_DEVICE;
+    }
     // join: the caller's stream continues after every chain
     for (int c = 1; c < chains; ++c) {
         SSD_HIP(env, hipEventRecord(env->chain_events[c - 1], env->chain_streams[c - 1]));
         SSD_HIP(env, hipStreamWaitEvent(s, env->chain_events[c - 1], 0));
     }
-    if (pipelined) {
-        (void)hipEventRecord(env->pipe_done, s);
-        std::lock_guard<std::mutex> lk(g_pipe_owners.mu);
-        g_pipe_owners.enqueuing[env->device & 63] = nullptr;
-    }
-    for (int c = 0; c < chains; ++c)
-        if (rcs[c]) { env->err = "kernel launch failed in ssd_rollout_random"; return rcs[c]; }
-    return SSD_OK;
+    if (rc_all) env->err = "kernel launch failed in ssd_rollout_random";
+    return rc_all;
 }
 
 int ssd_observe(ssd_env *env, void *obs, uint32_t flags, void *stream) {

@@ -74,14 +74,37 @@ struct Params {
     // A launch with pipe_flags waits, env by env, for pass pipe_seq - 1 instead of relying on stream order (see ssd_capi.hip).
     uint32_t *pipe_flags;
     uint32_t pipe_seq;
+    uint32_t coherent;             // the step launch moves state and outputs with agent-scope (sc1) accesses only (kernel: PIPE = 2); set by
+                                   // the library's own dispatch path for the map-specific uint8 kernels (ssd_aql.hip)
     uint32_t pipe_rotate;          // test knob (SSD_PIPE_ROTATE): shift the env -> workgroup mapping by this many workgroups per launch,
                                    // so that an env's consecutive steps run on different XCDs (workgroups go round-robin to XCDs)
+};
+
+// The kernarg segment of ssd_env_kernel: its nine leading arguments (repeated Params fields, 56 bytes: preloaded into SGPRs
+// by the command processor) followed by the parameter block.  Natural C layout == the code object's argument offsets.
+struct KernArgs {
+    uint4 *hdr; uint32_t *agents; uint8_t *world;
+    int32_t E, e_begin, epb, n_apple;
+    const uint32_t *apple_cells; const uint32_t *lut;
+    Params p;
+};
+static_assert(sizeof(KernArgs) == 56 + sizeof(Params), "kernarg layout");
+
+// One launch, fully resolved: instantiation (host stub of the __global__), geometry, dynamic LDS bytes, kernel arguments.
+struct Launch {
+    const void *fn = nullptr;
+    uint32_t grid_x = 0, block_x = 0, lds = 0;
+    KernArgs args;
 };
 
 size_t lds_bytes(const Params &p, int envs_per_block, bool f32);
 int envs_per_block(const Params &p, bool f32);
 int fast_profile(const Params &p, int game);    // which map-specific step kernel a launch gets (0: the general ones)
+bool select(const Params &p, int game, Launch *out);   // resolve a launch without issuing it
+void launch(const Launch &L, void *stream);            // hipLaunchKernel of a resolved launch
 void launch(const Params &p, int game, void *stream);
+const void *flag_kernel_fn();                          // ssd_flag_kernel's host stub (AQL join)
+void launch_signal_kernel(long long *signal_value, void *stream);   // AQL fork: zero an HSA signal from a HIP stream
 void launch_render_full(const Params &p, int e0, int count, uint8_t *rgb_dev, void *stream);
 
 }  // namespace ssd

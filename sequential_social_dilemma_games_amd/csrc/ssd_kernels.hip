@@ -128,6 +128,7 @@ __device__ __forceinline__ void unit_vec(int code, int &dr, int &dc) {
 // reads its data registers late, so a VALU write to one of them needs wait states after the store.
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // `wt` (wave-uniform, Params::obs_wt) picks the policy per launch: once a launch is many rounds of waves (above 16 384
 // envs per launch, two launches in flight) the kernel is bandwidth-bound, L2 merging of the 12-byte pieces matters more than the final flush, and ordinary
 // stores win (65 536 envs: 53.6 vs 69.4 us).
@@ -223,7 +224,11 @@ constexpr FastMap kFastMap[2][3] = {
 // scope release / acquire), and publishes its own right after the write-back -- before it renders the observations.  Waves
 // of step k+1 thus start env by env while step k's slower waves are still at work, and the ~1.5 us between dependent
 // launches disappears from the critical path.  The wait is bounded: a wave that gives up sets kStPipeTimeout.
-template <int GAME, int MODE, bool F32, int NA, bool STD, int FAST, bool PIPE = false>
+// PIPE = 2 ("coherent"): the memory discipline of PIPE without the counters.  The env's state, rewards, dones and
+// observations move with agent-scope (sc1) accesses only: nothing of a launch stays dirty in an XCD's L2 and nothing is read
+// through a CU's L1, so consecutive launches of a chain need no cache write-back / invalidate between them -- the library's own
+// dispatch queues (ssd_aql.hip) then order them with the packet's barrier bit alone (release fence NONE: -0.85 us per step).
+template <int GAME, int MODE, bool F32, int NA, bool STD, int FAST, int PIPE = 0>
 // The leading arguments repeat the Params fields the first global loads need (14 dwords).  Built with
 // -mllvm -amdgpu-kernarg-preload-count=14 the command processor delivers them in SGPRs when the wave starts, so the
 // loads of the env's state go out without first waiting ~0.3 us for a scalar load of the kernel arguments.
@@ -268,8 +273,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     uint8_t *s_occ = s_beam + S;
     uint8_t *s_view = roll ? s_occ + S + A0 : s_world;              // what the observations read: world <- agents <- beams
 
+    constexpr bool kCoh = PIPE != 0;                                 // state through memory with sc1 accesses
+    constexpr bool kFlag = PIPE == 1;                                // ... and ordered env by env through pass counters
     int blk = blockIdx.x;
-    if constexpr (PIPE) blk = (int)((blockIdx.x + p.pipe_seq * p.pipe_rotate) % gridDim.x);   // (test knob; 0 = identity)
+    if constexpr (kFlag) blk = (int)((blockIdx.x + p.pipe_seq * p.pipe_rotate) % gridDim.x);   // (test knob; 0 = identity)
     const int e = a_e_begin + blk * a_epb + wv;             // (a_epb = blockDim.x / 64, without the implicit-argument load)
     constexpr int mode = MODE;                               // compile-time: step / reset / observe
     bool active = e < a_E;                                   // wave-uniform
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     SSD_STAMP(0);
 
     bool pipe_timeout = false;
-    if constexpr (PIPE) {
+    if constexpr (kFlag) {
         if (active) {
             const uint32_t want = p.pipe_seq - 1u;
             uint32_t spins = 0;
@@ -299,10 +306,17 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // (PIPE: the env's state may have been written a moment ago by a wave on another XCD, i.e. behind another L2: agent-
         // scope loads and stores, dword by dword, instead of cache write-backs / invalidations around ordinary ones)
         auto cload = [](const uint32_t *ptr) -> uint32_t {
-            return PIPE ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ptr;
+            return kCoh ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ptr;
+        };
+        // 16 bytes with one agent-scope load.  (Inline asm: the compiler does not know the load is outstanding -- every use is
+        // behind the explicit s_waitcnt vmcnt(0) below; its own vmcnt waits only become more conservative by foreign entries.)
+        auto cload16 = [](const uint8_t *ptr) -> u32x4_t {
+            u32x4_t v;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory");
+            return v;
         };
         uint4 hdr;
-        if (PIPE) {
+        if (kCoh) {
             const uint32_t hv = cload(reinterpret_cast<const uint32_t *>(a_hdr + e) + (lane & 3));
             hdr = make_uint4(rl(hv, 0), rl(hv, 1), rl(hv, 2), rl(hv, 3));
         } else {
@@ -314,10 +328,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         if (mode != kModeReset && is_agent) areg = cload(a_agents + (size_t)e * N + lane);
         const uint8_t *gsrc = mode == kModeReset ? p.reset_world : a_world + (size_t)e * S;
         uint4 w0 = make_uint4(0, 0, 0, 0), b0 = make_uint4(0, 0, 0, 0);
+        u32x4_t w0c = {0u, 0u, 0u, 0u};                                 // (coherent variants: the asm load's destination)
         if (lane * 16 < S) {
-            if (PIPE) {
-                const uint32_t *g4 = reinterpret_cast<const uint32_t *>(gsrc + lane * 16);
-                w0 = make_uint4(cload(g4), cload(g4 + 1), cload(g4 + 2), cload(g4 + 3));
+            if (kCoh) {
+                w0c = cload16(gsrc + lane * 16);
             } else {
                 w0 = *reinterpret_cast<const uint4 *>(gsrc + lane * 16);
             }
@@ -353,6 +367,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             wlist[j] = 0u;
             if (GAME == 1 && 64 * j < n_waste) wlist[j] = (mode != kModeObserve && idx < n_waste) ? p.waste_cells[idx] : 0u;
         }
+        if (kCoh) {                                                      // (the asm load above)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0c) : : "memory");
+            w0 = make_uint4(w0c.x, w0c.y, w0c.z, w0c.w);
+        }
         uint32_t key = rfl(hdr.x), t = rfl(hdr.y), episode = rfl(hdr.z);
         s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b;
         if (obs_f32) { reinterpret_cast<float4 *>(s_f32)[lane] = flut; reinterpret_cast<float4 *>(s_f32)[lane + 64] = flut_b; }
@@ -374,9 +392,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         for (int i = lane * 16 + 1024; i < S; i += 1024) {   // maps above 1024 cells
             uint4 bv = make_uint4(0, 0, 0, 0);
             if (mode == kModeObserve && keep_beams) bv = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + i);
-            if (PIPE) {
-                const uint32_t *g4 = reinterpret_cast<const uint32_t *>(gsrc + i);
-                *reinterpret_cast<uint4 *>(s_world + i) = make_uint4(cload(g4), cload(g4 + 1), cload(g4 + 2), cload(g4 + 3));
+            if (kCoh) {
+                u32x4_t wv = cload16(gsrc + i);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wv) : : "memory");
+                *reinterpret_cast<uint4 *>(s_world + i) = make_uint4(wv.x, wv.y, wv.z, wv.w);
             } else {
                 *reinterpret_cast<uint4 *>(s_world + i) = *reinterpret_cast<const uint4 *>(gsrc + i);
             }
@@ -394,12 +413,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         uint32_t waste_cur = GAME == 1 ? rfl(hdr.w) >> 16 : 0u;
         auto write_state = [&]() {
             uint8_t *gw = a_world + (size_t)e * S;
-            if constexpr (PIPE) {
+            if constexpr (kCoh) {
                 auto cstore = [](uint32_t *ptr, uint32_t v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
                 for (int i = lane * 16; i < S; i += 64 * 16) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(s_world + i);
-                    uint32_t *g4 = reinterpret_cast<uint32_t *>(gw + i);
-                    cstore(g4, v.x); cstore(g4 + 1, v.y); cstore(g4 + 2, v.z); cstore(g4 + 3, v.w);
+                    const uint4 v4 = *reinterpret_cast<const uint4 *>(s_world + i);
+                    const u32x4_t v = {v4.x, v4.y, v4.z, v4.w};
+                    // one 16-byte write-through store (the s_nop: a store of more than 64 bits reads its data registers late)
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(gw + i), "v"(v) : "memory");
                 }
                 if (is_agent) cstore(a_agents + (size_t)e * N + lane, cell | (orient << 16));
                 if (lane < 4) cstore(reinterpret_cast<uint32_t *>(a_hdr + e) + lane,
@@ -407,9 +427,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 if (status && lane == 0) atomicOr(p.status, status);
                 // publish: once these stores have completed (they are write-through at agent scope, so no L2 write-back is
                 // needed -- but a workgroup-scope fence alone emits no wait for them) this env's next pass may start
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) cstore(p.pipe_flags + e, p.pipe_seq);
+                if constexpr (kFlag) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) cstore(p.pipe_flags + e, p.pipe_seq);
+                }
                 return;
             }
             for (int i = lane * 16; i < S; i += 64 * 16) {
@@ -1048,9 +1070,15 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 waste_last = waste_count;
                 if (!roll) write_state();
                 if (is_agent && is_step) {
-                    if (p.rew) p.rew[slot_en + (size_t)e * N + lane] = rew;             // compute_reward (:208)
-                    // get_done -> False (:209); with a horizon set, the episode ends after `horizon` steps
-                    if (p.done) p.done[slot_en + (size_t)e * N + lane] = (p.horizon > 0 && t >= (uint32_t)p.horizon) ? 1 : 0;
+                    // compute_reward (:208); get_done -> False (:209); with a horizon set, the episode ends after `horizon` steps
+                    const uint8_t dn = (p.horizon > 0 && t >= (uint32_t)p.horizon) ? 1 : 0;
+                    if constexpr (PIPE == 2) {                                          // (write-through: nothing stays dirty in L2)
+                        if (p.rew) __hip_atomic_store(p.rew + slot_en + (size_t)e * N + lane, rew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (p.done) __hip_atomic_store(p.done + slot_en + (size_t)e * N + lane, dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        if (p.rew) p.rew[slot_en + (size_t)e * N + lane] = rew;
+                        if (p.done) p.done[slot_en + (size_t)e * N + lane] = dn;
+                    }
                 }
                 wave_sync();
             }
@@ -1294,6 +1322,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             in_reset = to_reset == 0;
         }
         if (roll) write_state();
+        // (the launch that follows in the chain starts when this one has ended: every store of this wave has landed by then)
+        if constexpr (PIPE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     SSD_STAMP(9);       // observations issued
     SSD_STAMP_RT(11);
@@ -1317,20 +1347,27 @@ __global__ void ssd_render_full_kernel(const Params p, int e0, uint8_t *rgb) {
     }
 }
 
+// Host-side handle (the __global__ stub) of one instantiation: what hipLaunchKernel takes, and what names the kernel's
+// descriptor in the code object for the library's own AQL dispatches (ssd_aql.hip).
+template <int GAME, int MODE, bool F32, int NA, bool STD, int FAST, int PIPE = 0>
+static const void *kernel_fn() {
+    return reinterpret_cast<const void *>(&ssd_env_kernel<GAME, MODE, F32, NA, STD, FAST, PIPE>);
+}
+
 template <int GAME, bool F32, int NA, bool STD, int FAST>
-static void launch_step(const Params &p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+static const void *select_step(const Params &p) {
     if (p.mode == kModeRollout) {
-        if constexpr (!F32) hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeRollout, false, NA, STD, FAST>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
+        if constexpr (!F32) return kernel_fn<GAME, kModeRollout, false, NA, STD, FAST>();
+        return nullptr;
     } else if (p.mode == kModeStepAuto) {
-        if constexpr (!F32) hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStepAuto, false, NA, STD, FAST>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
+        if constexpr (!F32) return kernel_fn<GAME, kModeStepAuto, false, NA, STD, FAST>();
+        return nullptr;
     } else {
         if constexpr (!F32 && FAST != 0) {           // (the kernels rollouts of the known maps use)
-            if (p.pipe_flags) {
-                hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStep, false, NA, STD, FAST, true>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
-                return;
-            }
+            if (p.pipe_flags) return kernel_fn<GAME, kModeStep, false, NA, STD, FAST, 1>();
+            if (p.coherent) return kernel_fn<GAME, kModeStep, false, NA, STD, FAST, 2>();
         }
-        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeStep, F32, NA, STD, FAST>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
+        return kernel_fn<GAME, kModeStep, F32, NA, STD, FAST>();
     }
 }
 
@@ -1351,41 +1388,80 @@ int fast_profile(const Params &p, int game) {
 }
 
 template <int GAME, bool F32>
-static void launch_game(const Params &p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+static const void *select_game(const Params &p) {
     if (p.mode == kModeStep || p.mode == kModeRollout || p.mode == kModeStepAuto) {
         // specialised step kernels for the reference's configurations (view 7, beam 5; 5 or 10 agents), and
         // among those the FAST ones for the game's shipped map called in the plain way
         const bool std_view = p.view_len == 7 && p.beam_len == 5;
         const int fast = fast_profile(p, GAME);
         if (std_view && p.N == 5) {
-            if (fast == 1) launch_step<GAME, F32, 5, true, 1>(p, grid, block, lds, s);
-            else if (GAME == 0 && fast == 2) { if constexpr (GAME == 0) launch_step<GAME, F32, 5, true, 2>(p, grid, block, lds, s); }
-            else launch_step<GAME, F32, 5, true, 0>(p, grid, block, lds, s);
+            if (fast == 1) return select_step<GAME, F32, 5, true, 1>(p);
+            if (GAME == 0 && fast == 2) { if constexpr (GAME == 0) return select_step<GAME, F32, 5, true, 2>(p); }
+            return select_step<GAME, F32, 5, true, 0>(p);
         } else if (std_view && p.N == 10) {
-            if (fast == 1) launch_step<GAME, F32, 10, true, 1>(p, grid, block, lds, s);
-            else if (GAME == 1 && fast == 2) { if constexpr (GAME == 1) launch_step<GAME, F32, 10, true, 2>(p, grid, block, lds, s); }
-            else launch_step<GAME, F32, 10, true, 0>(p, grid, block, lds, s);
-        } else if (std_view) launch_step<GAME, F32, 0, true, 0>(p, grid, block, lds, s);
-        else launch_step<GAME, F32, 0, false, 0>(p, grid, block, lds, s);
+            if (fast == 1) return select_step<GAME, F32, 10, true, 1>(p);
+            if (GAME == 1 && fast == 2) { if constexpr (GAME == 1) return select_step<GAME, F32, 10, true, 2>(p); }
+            return select_step<GAME, F32, 10, true, 0>(p);
+        } else if (std_view) return select_step<GAME, F32, 0, true, 0>(p);
+        return select_step<GAME, F32, 0, false, 0>(p);
     } else if (p.mode == kModeReset) {
-        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeReset, F32, 0, false, 0>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
-    } else {
-        hipLaunchKernelGGL((ssd_env_kernel<GAME, kModeObserve, F32, 0, false, 0>), grid, block, lds, s, p.hdr, p.agents, p.world, p.E, p.e_begin, (int)(block.x >> 6), p.n_apple, p.apple_cells, p.lut, p);
+        if constexpr (!F32) { if (p.coherent) return kernel_fn<GAME, kModeReset, false, 0, false, 0, 2>(); }
+        return kernel_fn<GAME, kModeReset, F32, 0, false, 0>();
     }
+    return kernel_fn<GAME, kModeObserve, F32, 0, false, 0>();
 }
 
-void launch(const Params &p_in, int game, void *stream) {
+// Everything one launch of the fused kernel needs: which instantiation, its geometry, and the kernel arguments laid out as the
+// kernel's kernarg segment (KernArgs: 56 bytes of leading arguments the command processor preloads into SGPRs, then Params).
+bool select(const Params &p_in, int game, Launch *out) {
     Params p = p_in;
     static const int forced_wt = [] { const char *v = getenv("SSD_OBS_WT"); return v ? atoi(v) : -1; }();   // tuning override
     // per launch (rollouts run two launches at a time); float32 observations are 4x the bytes: a quarter of the envs
     p.obs_wt = forced_wt >= 0 ? forced_wt : ((p.E - p.e_begin) <= (p.obs_f32 ? 4096 : 16384) ? 1 : 0);
+    if (p.coherent) p.obs_wt = 1;                   // (a coherent launch leaves nothing dirty in L2)
+    static const int forced_epb = [] { const char *v = getenv("SSD_ENVS_PER_BLOCK"); return v ? atoi(v) : 0; }();
     const bool f32 = p.obs && p.obs_f32;            // the float32-observation variant is a separate instantiation
-    const int epb = envs_per_block(p, f32);
-    const dim3 grid((p.E - p.e_begin + epb - 1) / epb), block(64 * epb);
-    const size_t lds = lds_bytes(p, epb, f32);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (game == 0) { if (f32) launch_game<0, true>(p, grid, block, lds, s); else launch_game<0, false>(p, grid, block, lds, s); }
-    else { if (f32) launch_game<1, true>(p, grid, block, lds, s); else launch_game<1, false>(p, grid, block, lds, s); }
+    int epb = envs_per_block(p, f32);
+    // test knob of the coherent chains (ssd_capi.hip, SSD_AQL_ALTERNATE): half the envs per workgroup, i.e. another env ->
+    // workgroup -> XCD mapping than the launches before and after
+    if (p.coherent == 2 && epb > 1 && forced_epb <= 0) epb /= 2;
+    static const bool plain_exp = [] { const char *v = getenv("SSD_TEST_ALT_PLAIN"); return v && atoi(v) != 0; }();   // experiment
+    if (plain_exp) p.coherent = 0;
+    out->grid_x = (uint32_t)((p.E - p.e_begin + epb - 1) / epb);
+    out->block_x = (uint32_t)(64 * epb);
+    out->lds = (uint32_t)lds_bytes(p, epb, f32);
+    if (game == 0) out->fn = f32 ? select_game<0, true>(p) : select_game<0, false>(p);
+    else out->fn = f32 ? select_game<1, true>(p) : select_game<1, false>(p);
+    KernArgs &k = out->args;
+    k.hdr = p.hdr; k.agents = p.agents; k.world = p.world; k.E = p.E; k.e_begin = p.e_begin; k.epb = epb; k.n_apple = p.n_apple;
+    k.apple_cells = p.apple_cells; k.lut = p.lut; k.p = p;
+    return out->fn != nullptr;
+}
+
+void launch(const Launch &L, void *stream) {
+    KernArgs &k = const_cast<KernArgs &>(L.args);
+    void *args[] = {&k.hdr, &k.agents, &k.world, &k.E, &k.e_begin, &k.epb, &k.n_apple, &k.apple_cells, &k.lut, &k.p};
+    (void)hipLaunchKernel(L.fn, dim3(L.grid_x), dim3(L.block_x), args, L.lds, static_cast<hipStream_t>(stream));
+}
+
+void launch(const Params &p, int game, void *stream) {
+    Launch L;
+    if (select(p, game, &L)) launch(L, stream);
+}
+
+// Used by the library's own AQL queues (ssd_aql.hip): bump a counter in host-visible memory once everything before this
+// dispatch in its queue has completed (the dispatch carries the barrier bit): what the caller's HIP stream waits for.
+__global__ void ssd_flag_kernel(unsigned long long *flag) {
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ... and the other direction: a kernel on the caller's HIP stream that releases the library's queues (they wait, in a
+// barrier-AND packet, for this HSA signal's value to become 0) once the stream's earlier work is done.
+__global__ void ssd_signal_kernel(long long *signal_value) {
+    if (threadIdx.x == 0) __hip_atomic_store(signal_value, 0ll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+const void *flag_kernel_fn() { return reinterpret_cast<const void *>(&ssd_flag_kernel); }
+void launch_signal_kernel(long long *signal_value, void *stream) {
+    hipLaunchKernelGGL(ssd_signal_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), signal_value);
 }
 
 void launch_render_full(const Params &p, int e0, int count, uint8_t *rgb_dev, void *stream) {
