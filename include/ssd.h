@@ -11,7 +11,8 @@
  * Conventions: every call returns 0 on success or a negative SSD_E_* code and never
  * throws; the caller owns every buffer passed in (the engine only allocates its own
  * state); one handle = one device + one caller-chosen stream per call; calls on one
- * handle are not re-entrant, distinct handles are independent; there is no global state
+ * handle are not re-entrant, distinct handles are independent (a host-pointer call first waits for the stream of the handle's
+ * last device-pointer call when that is another stream, so mixing the two styles keeps program order); there is no global state
  * (the reference's module-global RNGs become per-handle seed + counters).  There is no
  * CPU backend: without a usable HIP device ssd_create fails with SSD_E_DEVICE.
  *
@@ -67,7 +68,12 @@ enum {
                                 the device with a fifth of it to spare (up to ~3200 envs of the shipped maps on MI355X); ignored otherwise, and while another handle's
                                 pipelined rollout is in flight on the device.  It pays while the
                                 device has room to spare: 2048 envs 5.7 -> 4.8 us per step, no gain at 4096.  A wave that waits in
-                                vain (tens of ms: the device is oversubscribed by other work) sets SSD_ST_PIPE_TIMEOUT. */
+                                vain (tens of ms: the device is oversubscribed by other work) sets SSD_ST_PIPE_TIMEOUT.
+                                The room-to-spare rule counts ONE process: the request is meant for a process that has the device to
+                                itself.  Other processes' kernels on the same device only delay the waves (tested: a second process
+                                stepping 4096 envs throughout leaves the results bit-exact and the status word 0); what would starve
+                                them is another process pinning most of the device's wave slots with kernels that themselves wait --
+                                the bounded wait and the status bit are the guard against that, not a proof. */
     SSD_OBS_F32 = 1u << 2    /* obs points at float32 [E,N,V,V,3] instead of uint8: the normalisation of map_env.py:199
                                 fused into the kernel (4x the observation bytes; a separate, slower mode) */
 };
@@ -162,6 +168,20 @@ int ssd_render_full(ssd_env *env, int32_t e, uint8_t *rgb);
  * visuallizer_rllib.py:161 take one env at a time with map_to_colors().  Device pointer (enqueued on `stream`, returns
  * at once) or, with SSD_HOST_PTRS, host pointer (returns when the frames have arrived).  No other flag applies. */
 int ssd_render_frames(ssd_env *env, int32_t e_begin, int32_t count, uint8_t *rgb, uint32_t flags, void *stream);
+
+/* The extra members of the observation dict of an env built with return_agent_actions=True (map_env.py:201-205 step,
+ * :242-246 reset, find_visible_agents :749-770; consumers run_scripts/train_moa.py:70, models/moa_model.py:216-249), for the
+ * whole batch, as device tensors (or host arrays with SSD_HOST_PTRS):
+ *   other_actions i64 [E,N,N-1]  row (e,i): this step's actions of the agents other than i, in the order of their ids sorted AS
+ *           STRINGS, i.e. `sorted(actions.keys())` ('agent-10' < 'agent-2').  An agent absent from the action dict (action -1)
+ *           contributes -1 in its place -- the reference's array is shorter then, the dict API mirror drops these entries.
+ *           actions == NULL is the reset form: all zeros.  Rows whose done_mask byte (u8 [E,N], may be NULL: ssd_step's done output)
+ *           is non-zero are zeros too -- the env was reset by the step launch (SSD_AUTO_RESET) or is about to be, and its
+ *           observation row is a reset's.
+ *   visible       i64 [E,N,N-1]  all ones: the reference tests the agent's OWN position against its window (:767).
+ * Either output may be NULL.  Needs no engine state: a pure function of `actions`. */
+int ssd_agent_action_obs(ssd_env *env, const int32_t *actions, const uint8_t *done_mask, int64_t *other_actions,
+                         int64_t *visible, uint32_t flags, void *stream);
 
 /* Episode length.  The reference's agents never report done; episodes end through RLlib's `horizon`
  * (run_scripts/train_baseline.py:131, train_moa.py:122).  horizon > 0: a step whose t reaches it writes

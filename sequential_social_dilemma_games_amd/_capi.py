@@ -17,7 +17,7 @@ ABI_VERSION = 1
 
 # every symbol include/ssd.h declares
 SYMBOLS = ("ssd_create", "ssd_destroy", "ssd_reset", "ssd_step", "ssd_step_random", "ssd_rollout_random", "ssd_set_rollout_chains", "ssd_observe",
-           "ssd_get_state", "ssd_set_state", "ssd_get_waste_count", "ssd_render_full", "ssd_render_frames", "ssd_set_horizon", "ssd_potential_waste_area",
+           "ssd_get_state", "ssd_set_state", "ssd_get_waste_count", "ssd_render_full", "ssd_render_frames", "ssd_agent_action_obs", "ssd_set_horizon", "ssd_potential_waste_area",
            "ssd_device_status", "ssd_synchronize", "ssd_last_error", "ssd_abi_version")
 
 
@@ -86,6 +86,7 @@ def lib():
         L.ssd_get_waste_count.argtypes = [vp, vp]
         L.ssd_render_full.argtypes = [vp, i32, vp]
         L.ssd_render_frames.argtypes = [vp, i32, i32, vp, u32, vp]
+        L.ssd_agent_action_obs.argtypes = [vp, vp, vp, vp, vp, u32, vp]
         L.ssd_set_horizon.argtypes = [vp, i32]
         L.ssd_potential_waste_area.argtypes = [vp]
         L.ssd_device_status.argtypes = [vp, C.POINTER(u32), C.c_int]

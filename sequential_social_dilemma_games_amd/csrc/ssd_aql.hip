@@ -164,9 +164,6 @@ DeviceCtx *device_ctx(int device) {
     if (off) { c.why = "SSD_AQL=0"; return nullptr; }
     if (!load_api()) { c.why = "HSA runtime unavailable"; return nullptr; }
     auto fail = [&](const std::string &m) -> DeviceCtx * { c.why = m; say(m); return nullptr; };
-    int can_wait = 0;
-    if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess || !can_wait)
-        return fail("device cannot hipStreamWaitValue");
     // the HSA agent behind HIP device `device`: same PCI function
     int dom = 0, bus = 0, dev = 0;
     if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, device) != hipSuccess ||
@@ -247,9 +244,8 @@ struct Queue {
     uint64_t rung = 0;                  // packets below this index have been handed to the doorbell
     uint32_t mask = 0;
     std::atomic<int> error{0};
-    unsigned long long *join_flag = nullptr;    // HIP signal memory: the flag kernel's counter
-    uint64_t join_seq = 0;                      // value the counter reaches after the last join enqueued
-    void *flag_kernarg = nullptr;               // (host kernarg pool) the flag kernel's one argument
+    uint32_t *abort_flag = nullptr;             // host memory the waiting kernel looks at: set on a queue error
+    void *flag_kernarg = nullptr;               // (host kernarg pool) the flag kernel's one argument: the join counter
     Kernel flag_kernel{};
     hsa_signal_t done_signal{};                 // experiment (SSD_AQL_SIGNAL=1): completion signal attached to every dispatch
 };
@@ -257,12 +253,13 @@ struct Queue {
 static void queue_error_cb(hsa_status_t status, hsa_queue_t *, void *data) {
     auto *Q = static_cast<Queue *>(data);
     Q->error.store((int)status ? (int)status : -1);
+    if (Q->abort_flag) *reinterpret_cast<volatile uint32_t *>(Q->abort_flag) = 1;
     const char *msg = nullptr;
     if (g_api.hsa_status_string) g_api.hsa_status_string(status, &msg);
     fprintf(stderr, "[ssd aql] queue error: %s\n", msg ? msg : "?");
 }
 
-Queue *queue_create(int device) {
+Queue *queue_create(int device, unsigned long long *join_counter, uint32_t *abort_flag) {
     DeviceCtx *c = device_ctx(device);
     if (!c) return nullptr;
     static const int skip = [] { const char *v = getenv("SSD_AQL_SKIP_QUEUES"); return v ? atoi(v) : 0; }();   // experiment: spacer queues
@@ -287,21 +284,7 @@ Queue *queue_create(int device) {
     if (with_signal) g_api.hsa_signal_create(1ll << 60, 0, nullptr, &Q->done_signal);
     Q->mask = Q->q->size - 1;
     Q->widx = Q->rung = g_api.hsa_queue_load_read_index_scacquire(Q->q);
-    void *flag = nullptr;
-    if (hipExtMallocWithFlags(&flag, 8, hipMallocSignalMemory) != hipSuccess || !flag) {
-        (void)hipGetLastError();
-        say("hipExtMallocWithFlags(hipMallocSignalMemory) failed");
-        g_api.hsa_queue_destroy(Q->q);
-        delete Q;
-        return nullptr;
-    }
-    Q->join_flag = static_cast<unsigned long long *>(flag);
-    if (hipStreamWriteValue64(nullptr, Q->join_flag, 0, 0) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
-        (void)hipGetLastError();
-        say("hipStreamWriteValue64 failed");
-        queue_destroy(Q);
-        return nullptr;
-    }
+    Q->abort_flag = abort_flag;
     bool ok = lookup(device, flag_kernel_fn(), &Q->flag_kernel);
     if (ok) ok = g_api.hsa_amd_memory_pool_allocate(c->host_kernarg_pool, 64, 0, &Q->flag_kernarg) == HSA_STATUS_SUCCESS &&
                  g_api.hsa_amd_agents_allow_access(1, &c->gpu, nullptr, Q->flag_kernarg) == HSA_STATUS_SUCCESS;
@@ -311,14 +294,13 @@ Queue *queue_create(int device) {
         return nullptr;
     }
     std::memset(Q->flag_kernarg, 0, 64);
-    std::memcpy(Q->flag_kernarg, &Q->join_flag, sizeof(void *));
+    std::memcpy(Q->flag_kernarg, &join_counter, sizeof(void *));
     return Q;
 }
 
 void queue_destroy(Queue *Q) {
     if (!Q) return;
     if (Q->q) g_api.hsa_queue_destroy(Q->q);
-    if (Q->join_flag) (void)hipFree(Q->join_flag);
     if (Q->flag_kernarg) g_api.hsa_amd_memory_pool_free(Q->flag_kernarg);
     delete Q;
 }
@@ -379,12 +361,11 @@ void ring(Queue *Q) {
 uint64_t write_index(const Queue *Q) { return Q->widx; }
 uint64_t read_index(const Queue *Q) { return g_api.hsa_queue_load_read_index_scacquire(Q->q); }
 
-// JOIN: after everything enqueued so far on Q, bump the queue's counter (system-scope release), and make `stream` wait for it.
-bool join(Queue *Q, void *stream) {
+// JOIN: after everything enqueued so far on Q, bump the join counter; the packet's system-scope release makes the rollout's
+// results visible to everybody.  (The caller's stream waits for the counter with ssd_wait_counter_kernel.)
+void join(Queue *Q) {
     dispatch(Q, Q->flag_kernel, 1, 64, 0, Q->flag_kernarg, /*barrier=*/true, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM);
     ring(Q);
-    Q->join_seq++;
-    return hipStreamWaitValue64(static_cast<hipStream_t>(stream), Q->join_flag, Q->join_seq, hipStreamWaitValueGte, ~0ull) == hipSuccess;
 }
 
 // FORK signals

@@ -12,7 +12,9 @@ bool available(int device);                        // HSA runtime reachable, age
 const char *why_not(int device);
 bool lookup(int device, const void *host_fn, Kernel *out);   // kernel descriptor of the instantiation behind a HIP host stub
 
-Queue *queue_create(int device);
+// `join_counter`: device memory, 8 bytes, zeroed; every join() on the queue adds 1 to it once the queue's earlier packets are done.
+// `abort_flag`: host memory (device-mapped), set to 1 when the runtime reports an error on the queue.
+Queue *queue_create(int device, unsigned long long *join_counter, uint32_t *abort_flag);
 void queue_destroy(Queue *q);
 bool queue_failed(const Queue *q);                 // the runtime reported an error on the queue (the path is then abandoned)
 uint64_t write_index(const Queue *q);              // index the next packet will get
@@ -23,7 +25,7 @@ void dispatch(Queue *q, const Kernel &k, uint32_t grid_x, uint32_t block_x, uint
               bool barrier, int acquire_scope, int release_scope);
 void barrier_and(Queue *q, uint64_t dep_signal_handle);      // the queue waits until the signal's value is 0
 void ring(Queue *q);                               // doorbell: hand everything written so far to the command processor
-bool join(Queue *q, void *hip_stream);             // `hip_stream` continues only after everything enqueued on q so far
+void join(Queue *q);                               // after everything enqueued on q so far: join_counter += 1 (and a system-scope release)
 
 uint64_t signal_create(long long initial);         // 0 on failure
 void signal_destroy(uint64_t handle);

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -61,6 +62,9 @@ struct AqlState {
     uint64_t fork_sig[kForks] = {};
     uint64_t fork_used[kForks][8] = {};             // index of the barrier packet that waits on the signal, per chain (+1; 0 = unused)
     int fork_next = 0;
+    unsigned long long *join_counter = nullptr;     // device memory: += 1 by every chain's last packet of a call
+    unsigned long long joins = 0;                   // value it reaches when everything enqueued so far is done
+    uint32_t *abort_flag = nullptr;                 // host memory (device-mapped): a queue reported an error
     struct Key {
         const void *obs = nullptr, *rew = nullptr, *done = nullptr;
         int32_t ring = 0, f32 = 0, num_actions = 0, chains = 0, horizon = 0, coherent = 0;
@@ -118,6 +122,11 @@ struct ssd_env {
     int rollout_chains = 0;           // 0 = automatic
     std::vector<std::unique_ptr<ChainWorker>> workers;   // workers[c - 1] enqueues chain c
     std::unique_ptr<AqlState> aql;                       // the library's own dispatch path (ssd_aql.hip), set up on first use
+    // The stream the last device-pointer call enqueued on.  A host-pointer call (which runs on the stream it is given, usually
+    // the NULL stream, and returns finished results) first waits for that stream when it is another one: a caller that
+    // mixes the two styles -- tensors on a non-blocking side stream, then a *_host call -- gets program order.
+    hipStream_t last_stream = nullptr;
+    bool last_stream_set = false;
     std::string err;
 };
 
@@ -250,11 +259,16 @@ int run(ssd_env *env, int mode, const int32_t *actions, const uint8_t *order, co
     p.mode = mode; p.rotate = rotate; p.num_actions_random = num_actions_random;
     if (!host) {
         if (obs && (reinterpret_cast<uintptr_t>(obs) & 3u)) { env->err = "obs must be 4-byte aligned"; return SSD_E_INVALID; }
+        env->last_stream = s; env->last_stream_set = true;
         p.actions = actions; p.order = order; p.mask = mask; p.actions_out = actions_out;
         p.obs = obs; p.rew = rew; p.done = done;
         ssd::launch(p, env->game, stream);
         SSD_HIP(env, hipGetLastError());
         return SSD_OK;
+    }
+    if (env->last_stream_set && env->last_stream != s) {
+        SSD_HIP(env, hipStreamSynchronize(env->last_stream));
+        env->last_stream_set = false;
     }
     int rc = ensure_staging(env);
     if (rc) return rc;
@@ -688,6 +702,8 @@ static void aql_teardown(ssd_env *env) {
     AqlState &A = *env->aql;
     for (int c = 0; c < 8; ++c) if (A.q[c]) ssd::aql::queue_destroy(A.q[c]);
     for (uint64_t h : A.fork_sig) ssd::aql::signal_destroy(h);
+    if (A.join_counter) (void)hipFree(A.join_counter);
+    if (A.abort_flag) (void)hipHostFree(A.abort_flag);
     for (auto &st : A.sets) if (st.dev) (void)hipFree(st.dev);
     env->aql.reset();
 }
@@ -704,10 +720,25 @@ static bool aql_ready(ssd_env *env, int chains) {
             A.fork_sig[i] = ssd::aql::signal_create(0);
             if (!A.fork_sig[i]) return false;
         }
+        void *ptr = nullptr;
+        if (hipMalloc(&ptr, 8) != hipSuccess || hipMemset(ptr, 0, 8) != hipSuccess) { (void)hipGetLastError(); return false; }
+        A.join_counter = static_cast<unsigned long long *>(ptr);
+        if (hipHostMalloc(&ptr, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
+        A.abort_flag = static_cast<uint32_t *>(ptr);
+        *A.abort_flag = 0;
+        {   // first launches of the two helper kernels now (the runtime resolves a kernel on its first launch: ~50 us), not
+            // inside somebody's first short rollout
+            void *abort_dev = nullptr;
+            (void)hipHostGetDevicePointer(&abort_dev, A.abort_flag, 0);
+            ssd::aql::signal_set(A.fork_sig[0], 1);
+            ssd::launch_signal_kernel(ssd::aql::signal_value_ptr(A.fork_sig[0]), nullptr);
+            ssd::launch_wait_counter_kernel(A.join_counter, 0, static_cast<const uint32_t *>(abort_dev), nullptr);
+            if (hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipGetLastError(); return false; }
+        }
         A.ok = true;
     }
     while (A.nq < chains) {
-        A.q[A.nq] = ssd::aql::queue_create(env->device);
+        A.q[A.nq] = ssd::aql::queue_create(env->device, A.join_counter, A.abort_flag);
         if (!A.q[A.nq]) { A.ok = false; return false; }
         A.nq++;
     }
@@ -830,14 +861,16 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
         }
     }
     // JOIN: the caller's stream continues after every chain
-    bool ok = true;
-    static const bool host_join = [] { const char *v = getenv("SSD_AQL_HOST_JOIN"); return v && atoi(v) != 0; }();   // experiment: no stream wait, the call blocks
+    // JOIN: every chain ends by bumping the join counter; a one-wave kernel on the caller's stream sleeps until all have
     for (int c = 0; c < chains; ++c) {
-        if (host_join) { ssd::aql::ring(A.q[c]); while (ssd::aql::read_index(A.q[c]) < ssd::aql::write_index(A.q[c])) __builtin_ia32_pause(); }
-        else ok = ssd::aql::join(A.q[c], s) && ok;
+        ssd::aql::join(A.q[c]);
         st->last_use[c] = ssd::aql::write_index(A.q[c]);
     }
-    if (!ok) { (void)hipGetLastError(); env->err = "hipStreamWaitValue64 failed"; A.ok = false; return SSD_E_DEVICE; }
+    A.joins += (unsigned long long)chains;
+    void *abort_dev = nullptr;
+    (void)hipHostGetDevicePointer(&abort_dev, A.abort_flag, 0);
+    ssd::launch_wait_counter_kernel(A.join_counter, A.joins, static_cast<const uint32_t *>(abort_dev), s);
+    if (hipGetLastError() != hipSuccess) { env->err = "join kernel launch failed"; A.ok = false; return SSD_E_DEVICE; }
     for (int c = 0; c < chains; ++c) if (ssd::aql::queue_failed(A.q[c])) { env->err = "the HSA runtime reported an error on a dispatch queue"; A.ok = false; return SSD_E_DEVICE; }
     return SSD_OK;
 }
@@ -858,6 +891,7 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
         if (hipGetDevice(&cur) != hipSuccess || cur != env->device) SSD_HIP(env, hipSetDevice(env->device));
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    env->last_stream = s; env->last_stream_set = true;
     uint8_t *o = static_cast<uint8_t *>(obs);
     // Pipelined launches (SSD_ROLLOUT_PIPELINED; SSD_ROLLOUT_PIPELINE=1 / 0 in the environment forces / forbids them): only the
     // known maps' uint8 kernels have the variant, consecutive steps must not share an output slot, and the launches that can
@@ -1149,6 +1183,45 @@ int ssd_render_full(ssd_env *env, int32_t e, uint8_t *rgb) {
     SSD_HIP(env, hipSetDevice(env->device));
     SSD_HIP(env, hipDeviceSynchronize());              // (this entry point takes no stream: order it after everything enqueued)
     return ssd_render_frames(env, e, 1, rgb, SSD_HOST_PTRS, nullptr);
+}
+
+int ssd_agent_action_obs(ssd_env *env, const int32_t *actions, const uint8_t *done_mask, int64_t *other_actions, int64_t *visible,
+                         uint32_t flags, void *stream) {
+    if (!env) return SSD_E_INVALID;
+    if (flags & ~(uint32_t)SSD_HOST_PTRS) { env->err = "ssd_agent_action_obs: only SSD_HOST_PTRS is meaningful here"; return SSD_E_INVALID; }
+    const int E = env->E, N = env->N;
+    if (N < 2 || (!other_actions && !visible)) return SSD_OK;           // (N - 1 == 0 columns)
+    SSD_HIP(env, hipSetDevice(env->device));
+    ssd::AgentOrder ord;
+    {   // ids 'agent-<i>' sorted as strings (harvest.py:50, map_env.py:202)
+        std::vector<std::pair<std::string, int>> ids;
+        for (int i = 0; i < N; ++i) ids.emplace_back("agent-" + std::to_string(i), i);
+        std::sort(ids.begin(), ids.end());
+        std::memset(&ord, 0, sizeof(ord));
+        for (int r = 0; r < N; ++r) { ord.sorted[r] = (uint8_t)ids[r].second; ord.rank[ids[r].second] = (uint8_t)r; }
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t en = (size_t)E * N, out_n = en * (size_t)(N - 1);
+    if (!(flags & SSD_HOST_PTRS)) {
+        ssd::launch_agent_action_obs(actions, done_mask, reinterpret_cast<long long *>(other_actions), reinterpret_cast<long long *>(visible), ord, E, N, stream);
+        SSD_HIP(env, hipGetLastError());
+        return SSD_OK;
+    }
+    // host arrays: staged through scratch device buffers of this call (a convenience surface, not a fast path)
+    int32_t *d_act = nullptr; uint8_t *d_mask = nullptr; long long *d_out = nullptr, *d_vis = nullptr;
+    auto cleanup = [&]() { if (d_act) (void)hipFree(d_act); if (d_mask) (void)hipFree(d_mask); if (d_out) (void)hipFree(d_out); if (d_vis) (void)hipFree(d_vis); };
+    auto fail = [&](const char *what) { env->err = what; cleanup(); return SSD_E_DEVICE; };
+    if (actions) { if (hipMalloc(&d_act, en * 4) != hipSuccess || hipMemcpyAsync(d_act, actions, en * 4, hipMemcpyHostToDevice, s) != hipSuccess) return fail("staging actions"); }
+    if (done_mask) { if (hipMalloc(&d_mask, en) != hipSuccess || hipMemcpyAsync(d_mask, done_mask, en, hipMemcpyHostToDevice, s) != hipSuccess) return fail("staging done_mask"); }
+    if (other_actions && hipMalloc(&d_out, out_n * 8) != hipSuccess) return fail("staging other_actions");
+    if (visible && hipMalloc(&d_vis, out_n * 8) != hipSuccess) return fail("staging visible");
+    ssd::launch_agent_action_obs(d_act, d_mask, d_out, d_vis, ord, E, N, stream);
+    if (hipGetLastError() != hipSuccess) return fail("kernel launch");
+    if (other_actions && hipMemcpyAsync(other_actions, d_out, out_n * 8, hipMemcpyDeviceToHost, s) != hipSuccess) return fail("copy back");
+    if (visible && hipMemcpyAsync(visible, d_vis, out_n * 8, hipMemcpyDeviceToHost, s) != hipSuccess) return fail("copy back");
+    if (hipStreamSynchronize(s) != hipSuccess) return fail("synchronize");
+    cleanup();
+    return SSD_OK;
 }
 
 int ssd_set_horizon(ssd_env *env, int32_t horizon) {

@@ -97,6 +97,12 @@ struct Launch {
     KernArgs args;
 };
 
+// Agent indices in the order of their ids sorted as strings ('agent-0', 'agent-1', 'agent-10', 'agent-11', 'agent-2', ...: what
+// `sorted(actions.keys())` gives, map_env.py:202), and each index's rank in that order.
+struct AgentOrder { uint8_t sorted[kMaxAgents]; uint8_t rank[kMaxAgents]; };
+void launch_agent_action_obs(const int32_t *actions, const uint8_t *done_mask, long long *other_actions, long long *visible,
+                             const AgentOrder &order, int E, int N, void *stream);
+
 size_t lds_bytes(const Params &p, int envs_per_block, bool f32);
 int envs_per_block(const Params &p, bool f32);
 int fast_profile(const Params &p, int game);    // which map-specific step kernel a launch gets (0: the general ones)
@@ -104,6 +110,7 @@ bool select(const Params &p, int game, Launch *out);   // resolve a launch witho
 void launch(const Launch &L, void *stream);            // hipLaunchKernel of a resolved launch
 void launch(const Params &p, int game, void *stream);
 const void *flag_kernel_fn();                          // ssd_flag_kernel's host stub (AQL join)
+void launch_wait_counter_kernel(const unsigned long long *counter, unsigned long long target, const uint32_t *abort, void *stream);
 void launch_signal_kernel(long long *signal_value, void *stream);   // AQL fork: zero an HSA signal from a HIP stream
 void launch_render_full(const Params &p, int e0, int count, uint8_t *rgb_dev, void *stream);
 

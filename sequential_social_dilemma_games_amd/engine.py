@@ -323,6 +323,33 @@ class VecEngine(object):
             _capi.check(self._L.ssd_render_frames(self._h, int(e_begin), count, self._dp(out), 0, self._stream()), self._h)
         return out
 
+    def agent_action_obs(self, actions=None, done=None, out=None):
+        """The `other_agent_actions` / `visible_agents` members of the reference's observation dict under
+        return_agent_actions=True (map_env.py:201-205, :242-246, :749-770) for the whole batch: int64 [E,N,N-1] device tensors.
+        actions: this step's int32 [E,N] actions (None: the reset form, zeros); done: optional u8 [E,N] (rows of envs that the
+        step reset, or is about to, are zeros).  Row (e,i) lists the OTHER agents' actions in string-sorted id order, -1 for an
+        agent that did not act.  visible_agents is all ones (the reference's quirk, :767)."""
+        torch, dev = self._torch()
+        shape = (self.E, self.N, max(self.N - 1, 0))
+        if actions is not None:
+            self._check_tensor(actions, (self.E, self.N), torch.int32, "actions")
+        if done is not None:
+            self._check_tensor(done, (self.E, self.N), torch.uint8, "done")
+        oaa, vis = out if out is not None else (torch.empty(shape, dtype=torch.int64, device=dev), torch.empty(shape, dtype=torch.int64, device=dev))
+        for t, name in ((oaa, "other_agent_actions"), (vis, "visible_agents")):
+            self._check_tensor(t, shape, torch.int64, name)
+        _capi.check(self._L.ssd_agent_action_obs(self._h, self._dp(actions), self._dp(done), self._dp(oaa), self._dp(vis), 0,
+                                                 self._stream()), self._h)
+        return oaa, vis
+
+    def agent_action_obs_host(self, actions=None, done=None):
+        shape = (self.E, self.N, max(self.N - 1, 0))
+        oaa, vis = np.zeros(shape, np.int64), np.zeros(shape, np.int64)
+        a = None if actions is None else np.ascontiguousarray(actions, dtype=np.int32).reshape(self.E, self.N)
+        d = None if done is None else np.ascontiguousarray(done, dtype=np.uint8).reshape(self.E, self.N)
+        _capi.check(self._L.ssd_agent_action_obs(self._h, _ptr(a), _ptr(d), _ptr(oaa), _ptr(vis), _capi.SSD_HOST_PTRS, None), self._h)
+        return oaa, vis
+
     def status(self, clear=True):
         st = C.c_uint32(0)
         _capi.check(self._L.ssd_device_status(self._h, C.byref(st), int(clear)), self._h)

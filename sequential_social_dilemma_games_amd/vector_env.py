@@ -23,21 +23,33 @@ _NORMALISE = (np.arange(256, dtype=np.float64) - 128.0) / 255.0
 
 class SSDVectorEnv(object):
     def __init__(self, game, num_envs, num_agents, horizon=1000, ascii_map=None, seed=0, device=0,
-                 env_index_base=0, view_len=K.VIEW_LEN, float32_obs=False):
+                 env_index_base=0, view_len=K.VIEW_LEN, float32_obs=False, return_agent_actions=False):
         self.engine = VecEngine(game, ascii_map, num_envs=num_envs, num_agents=num_agents, seed=seed, device=device,
                                 env_index_base=env_index_base, view_len=view_len)
         self.num_envs, self.num_agents, self.horizon = num_envs, num_agents, int(horizon)
         self.float32_obs = bool(float32_obs)     # the kernel writes float32((u8 - 128) / 255) NHWC directly
         self.engine.set_horizon(self.horizon)
         self.agent_ids = ['agent-%d' % i for i in range(num_agents)]
+        # return_agent_actions=True (the MOA trainers' envs, run_scripts/train_moa.py:70): observations become a dict
+        # {"curr_obs", "other_agent_actions" int64 [E,N,N-1], "visible_agents" int64 [E,N,N-1]} of device tensors -- the
+        # reference's per-agent observation dict (map_env.py:201-205, :242-246) batched (engine.agent_action_obs)
+        self.return_agent_actions = bool(return_agent_actions)
         self._out = None
+        self._extras = None
+        self._act_buf = None
         self._pending = None
 
     # ------------------------------------------------------------------ tensor API
+    def _wrap(self, obs, actions, done):
+        if not self.return_agent_actions:
+            return obs
+        self._extras = self.engine.agent_action_obs(actions, done, out=self._extras)
+        return {"curr_obs": obs, "other_agent_actions": self._extras[0], "visible_agents": self._extras[1]}
+
     def reset(self):
         self._out = self.engine.alloc_outputs(float32=self.float32_obs)
         self.engine.reset(obs=self._out[0])
-        return self._out[0]
+        return self._wrap(self._out[0], None, None)
 
     # Auto-reset, three ways.  (1) While every env was last reset by the same call (the engine keeps count) they all reach the
     # horizon on the same step and the host knows which one: nothing to launch until then, a full reset then.  (2) Otherwise
@@ -64,13 +76,17 @@ class SSDVectorEnv(object):
         in_kernel = self._in_kernel()
         obs, rew, done = self.engine.step(actions, out=self._out, auto_reset=in_kernel)
         self._auto_reset(obs, done, in_kernel)
-        return obs, rew, done
+        # (rows of envs whose episode just ended carry a reset's observation: their other_agent_actions are the reset's zeros)
+        return self._wrap(obs, actions, done if self.horizon > 0 else None), rew, done
 
     def step_random(self):
         in_kernel = self._in_kernel()
-        obs, rew, done = self.engine.step_random(out=self._out, auto_reset=in_kernel)
+        if self.return_agent_actions and self._act_buf is None:
+            import torch
+            self._act_buf = torch.empty((self.num_envs, self.num_agents), dtype=torch.int32, device=self._out[1].device)
+        obs, rew, done = self.engine.step_random(out=self._out, actions_out=self._act_buf, auto_reset=in_kernel)
         self._auto_reset(obs, done, in_kernel)
-        return obs, rew, done
+        return self._wrap(obs, self._act_buf, done if self.horizon > 0 else None), rew, done
 
     @staticmethod
     def to_float(obs):
@@ -88,14 +104,25 @@ class SSDVectorEnv(object):
         if self.float32_obs:
             raise RuntimeError("the dict surface renormalises uint8 observations: construct with float32_obs=False")
         if self._pending is None:
-            obs = self.reset().cpu().numpy()
+            obs = self.reset()
             rew = np.zeros((self.num_envs, self.num_agents), np.int32)
             done = np.zeros((self.num_envs, self.num_agents), np.uint8)
         else:
-            obs, rew, done = (x.cpu().numpy() for x in self._pending)
+            obs, rew, done = self._pending
+            rew, done = rew.cpu().numpy(), done.cpu().numpy()
+        oaa = vis = None
+        if self.return_agent_actions:
+            oaa, vis = obs["other_agent_actions"].cpu().numpy(), obs["visible_agents"].cpu().numpy()
+            obs = obs["curr_obs"]
+        obs = obs.cpu().numpy()
         o, r, d, i = {}, {}, {}, {}
         for e in range(self.num_envs):
-            o[e] = {a: _NORMALISE[obs[e, k]] for k, a in enumerate(self.agent_ids)}
+            if self.return_agent_actions:
+                # (an agent that sent no action is absent from the reference's array: drop its -1)
+                o[e] = {a: {"curr_obs": _NORMALISE[obs[e, k]], "other_agent_actions": oaa[e, k][oaa[e, k] >= 0],
+                            "visible_agents": vis[e, k]} for k, a in enumerate(self.agent_ids)}
+            else:
+                o[e] = {a: _NORMALISE[obs[e, k]] for k, a in enumerate(self.agent_ids)}
             r[e] = {a: int(rew[e, k]) for k, a in enumerate(self.agent_ids)}
             d[e] = {a: bool(done[e, k]) for k, a in enumerate(self.agent_ids)}
             d[e]["__all__"] = bool(done[e].any()) if self.num_agents else False
@@ -118,4 +145,8 @@ class SSDVectorEnv(object):
         if self._out is None:
             self._out = self.engine.alloc_outputs(float32=self.float32_obs)
         self.engine.reset(mask=mask, obs=self._out[0])
+        if self.return_agent_actions:
+            n1 = max(self.num_agents - 1, 0)
+            return {a: {"curr_obs": _NORMALISE[self._out[0][env_id, k].cpu().numpy()], "other_agent_actions": np.zeros(n1, np.int64),
+                        "visible_agents": np.ones(n1, np.int64)} for k, a in enumerate(self.agent_ids)}
         return {a: _NORMALISE[self._out[0][env_id, k].cpu().numpy()] for k, a in enumerate(self.agent_ids)}

@@ -1,0 +1,190 @@
+"""Rows f2 and f3 of SURVEY.md section 8 pinned to the reference (tests/golden/extras/x*.npz, recorded from the imported
+reference by tests/golden/gen_golden_extras.py with HarvestEnv / CleanupEnv(return_agent_actions=True)):
+  * the observation dict's `other_agent_actions` / `visible_agents` (map_env.py:201-205, :242-246, :749-770) -- the dict API
+    mirror, the batched tensors of VecEngine.agent_action_obs and SSDVectorEnv(return_agent_actions=True);
+  * full frames `env.map_to_colors()` (map_env.py:316-339) -- ssd_render_full / ssd_render_frames.
+CPU part: the oracle replays the same transitions, and the frame a test would rebuild from oracle state equals the
+reference's frame (so that tests which compare the engine's frames with such an overlay compare with the reference)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as G
+from oracle import pyoracle
+from sequential_social_dilemma_games_amd import constants as K
+
+XDIR = os.path.join(G.GOLDEN_DIR, "extras")
+NAMES = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(XDIR, "*.npz")))]
+
+
+def xload(name):
+    return G.Group(os.path.join(XDIR, name + ".npz"))
+
+
+def frame_from_state(world, beam, pos, lut):
+    """get_map_with_agents (map_env.py:280-302) + map_to_colors (:316-339) restated on plain state arrays."""
+    grid = world.astype(np.uint8).copy()
+    for i, (r, c) in enumerate(pos):
+        grid[r, c] = ord(str(int(str(i)[-1]) + 1)[0])
+    m = beam != 0
+    grid[m] = beam[m].astype(np.uint8)
+    return lut[grid]
+
+
+def test_extras_fixtures_exist():
+    assert len(NAMES) >= 5
+    assert any("n12" in n for n in NAMES) and any("subsets" in n for n in NAMES)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_replays_the_extras_and_rebuilds_their_frames(name):
+    g = xload(name)
+    lut = G.default_lut()
+    o = pyoracle.Oracle(g.game, g.map, 1, g.N, lut, view_len=g.view_len, seed=g.seed, env_base=g.env)
+    s = g.steps
+    for k in range(g.n_steps):
+        o.set_state(world=s["pre_world"][k][None], beam=np.zeros_like(s["pre_world"][k][None]), pos=s["pre_pos"][k][None],
+                    orient=s["pre_orient"][k][None], episode=np.array([s["episode"][k]], np.uint32), t=np.array([s["t"][k] - 1], np.uint32))
+        obs, rew, _ = o.step(s["act"][k][None], order=s["order"][k][None])
+        st = o.get_state()
+        for key in ("pos", "orient", "world", "beam"):
+            np.testing.assert_array_equal(st[key][0], s[key][k], err_msg="%s step %d %s" % (name, k, key))
+        np.testing.assert_array_equal(rew[0], s["rew"][k])
+        np.testing.assert_array_equal(obs[0], s["obs"][k])
+        np.testing.assert_array_equal(frame_from_state(st["world"][0], st["beam"][0], st["pos"][0], lut), s["frame"][k],
+                                      err_msg="%s: frame of step %d" % (name, k))
+    r = g.resets
+    for k in range(g.n_resets):
+        ep = int(r["episode"][k])
+        o.set_state(episode=np.array([(ep - 1) & 0xFFFFFFFF], np.uint32))
+        obs = o.reset()
+        st = o.get_state()
+        np.testing.assert_array_equal(obs[0], r["obs"][k])
+        np.testing.assert_array_equal(frame_from_state(st["world"][0], st["beam"][0], st["pos"][0], lut), r["frame"][k])
+        assert not r["oaa"][k].any() and (r["vis"][k] == 1).all()
+
+
+def sorted_others(N, i):
+    ids = sorted(range(N), key=lambda j: "agent-%d" % j)
+    return [j for j in ids if j != i]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_fixture_other_agent_actions_follow_the_documented_rule(name):
+    """What the engine implements, checked against the reference's arrays on the CPU: row i = actions of the others in
+    string-sorted id order, absent agents dropped; visible_agents all ones."""
+    g = xload(name)
+    s = g.steps
+    for k in range(g.n_steps):
+        act = s["act"][k]
+        for i in range(g.N):
+            want = [int(act[j]) for j in sorted_others(g.N, i) if act[j] >= 0]
+            n = int(s["oaa_len"][k][i])
+            assert n == len(want)
+            np.testing.assert_array_equal(s["oaa"][k][i][:n], want)
+        assert (s["vis"][k] == 1).all()
+
+
+# ----------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_engine_replays_extras_frames_and_agent_action_tensors(name):
+    """Through the C ABI: every recorded transition stepped from its pre-state; observations, rewards, state, the full frame
+    (ssd_render_full) and the batched other_agent_actions / visible_agents equal the reference's."""
+    from sequential_social_dilemma_games_amd.engine import VecEngine
+    g = xload(name)
+    eng = VecEngine(g.game, g.map, num_envs=1, num_agents=g.N, view_len=g.view_len, seed=g.seed, env_index_base=g.env, keep_beams=True)
+    s = g.steps
+    for k in range(g.n_steps):
+        eng.set_state(world=s["pre_world"][k][None], beam=np.zeros_like(s["pre_world"][k][None]), pos=s["pre_pos"][k][None],
+                      orient=s["pre_orient"][k][None], episode=np.array([s["episode"][k]], np.uint32), t=np.array([s["t"][k] - 1], np.uint32))
+        obs, rew, _ = eng.step_host(s["act"][k][None], s["order"][k][None])
+        np.testing.assert_array_equal(obs[0], s["obs"][k], err_msg="%s step %d" % (name, k))
+        np.testing.assert_array_equal(rew[0], s["rew"][k])
+        np.testing.assert_array_equal(eng.render_full(0), s["frame"][k], err_msg="%s: frame of step %d" % (name, k))
+        oaa, vis = eng.agent_action_obs_host(s["act"][k][None])
+        assert oaa.dtype == np.int64 and oaa.shape == (1, g.N, g.N - 1)
+        for i in range(g.N):
+            row = oaa[0, i]
+            n = int(s["oaa_len"][k][i])
+            np.testing.assert_array_equal(row[row >= 0], s["oaa"][k][i][:n], err_msg="%s step %d agent %d" % (name, k, i))
+            assert (row >= 0).sum() == n
+        np.testing.assert_array_equal(vis[0], s["vis"][k])
+    r = g.resets
+    for k in range(g.n_resets):
+        ep = int(r["episode"][k])
+        eng.set_state(episode=np.array([(ep - 1) & 0xFFFFFFFF], np.uint32))
+        np.testing.assert_array_equal(eng.reset_host()[0], r["obs"][k])
+        np.testing.assert_array_equal(eng.render_full(0), r["frame"][k])
+        oaa, vis = eng.agent_action_obs_host(None)
+        np.testing.assert_array_equal(oaa[0], r["oaa"][k])
+        np.testing.assert_array_equal(vis[0], r["vis"][k])
+    assert eng.status() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_dict_mirror_returns_the_reference_observation_dict(name):
+    """HarvestEnv / CleanupEnv(return_agent_actions=True) of the package: each agent's dict equals the reference's, member by
+    member (float64 curr_obs, int64 other_agent_actions of the right LENGTH when only a subset acts, visible_agents)."""
+    from sequential_social_dilemma_games_amd.harvest import HarvestEnv
+    from sequential_social_dilemma_games_amd.cleanup import CleanupEnv
+    g = xload(name)
+    cls = HarvestEnv if g.game == K.GAME_HARVEST else CleanupEnv
+    env = cls(g.map, num_agents=g.N, return_agent_actions=True, seed=g.seed, env_index=g.env)
+    s = g.steps
+    ids = ["agent-%d" % i for i in range(g.N)]
+    for k in range(0, g.n_steps, 3):
+        env._engine.set_state(world=s["pre_world"][k][None], beam=np.zeros_like(s["pre_world"][k][None]), pos=s["pre_pos"][k][None],
+                              orient=s["pre_orient"][k][None], episode=np.array([s["episode"][k]], np.uint32),
+                              t=np.array([s["t"][k] - 1], np.uint32))
+        env._dirty()
+        actions = {}
+        for idx in s["order"][k]:
+            if idx == 0xFF:
+                break
+            actions[ids[idx]] = int(s["act"][k][idx])
+        obs, rew, dones, info = env.step(actions)
+        for i, a in enumerate(ids):
+            d = obs[a]
+            assert set(d) == {"curr_obs", "other_agent_actions", "visible_agents"}
+            assert d["curr_obs"].dtype == np.float64
+            np.testing.assert_array_equal(d["curr_obs"], (s["obs"][k][i].astype(np.float64) - 128.0) / 255.0)
+            n = int(s["oaa_len"][k][i])
+            assert d["other_agent_actions"].dtype == np.int64 and d["other_agent_actions"].shape == (n,)
+            np.testing.assert_array_equal(d["other_agent_actions"], s["oaa"][k][i][:n])
+            np.testing.assert_array_equal(d["visible_agents"], s["vis"][k][i])
+            assert rew[a] == s["rew"][k][i]
+        np.testing.assert_array_equal(env.map_to_colors(), s["frame"][k])
+    env.close()
+
+
+@pytest.mark.gpu
+def test_vector_env_batches_the_observation_dict():
+    """SSDVectorEnv(return_agent_actions=True): {"curr_obs", "other_agent_actions", "visible_agents"} as device tensors for
+    a whole batch, consistent with the per-env rule the fixtures pin; rows of envs that the step reset are a reset's zeros."""
+    import torch
+    from sequential_social_dilemma_games_amd.vector_env import SSDVectorEnv
+    E, N = 37, 12
+    vec = SSDVectorEnv(K.GAME_HARVEST, E, N, horizon=4, seed=5, return_agent_actions=True)
+    obs = vec.reset()
+    assert set(obs) == {"curr_obs", "other_agent_actions", "visible_agents"}
+    assert obs["other_agent_actions"].dtype == torch.int64 and tuple(obs["other_agent_actions"].shape) == (E, N, N - 1)
+    assert not obs["other_agent_actions"].any() and bool((obs["visible_agents"] == 1).all())
+    rng = np.random.RandomState(0)
+    for t in range(1, 10):
+        act = rng.randint(0, 8, size=(E, N)).astype(np.int32)
+        act[rng.rand(E, N) < 0.1] = -1
+        obs, rew, done = vec.step(torch.from_numpy(act).cuda())
+        oaa = obs["other_agent_actions"].cpu().numpy()
+        finished = done.cpu().numpy()[:, 0] != 0
+        assert finished.all() == (t % 4 == 0)
+        for e in range(0, E, 5):
+            for i in range(N):
+                want = np.zeros(N - 1, np.int64) if finished[e] else np.array([act[e, j] for j in sorted_others(N, i)], np.int64)
+                np.testing.assert_array_equal(oaa[e, i], want)
+        assert bool((obs["visible_agents"] == 1).all())
+    o, r, d, i, _ = vec.poll()
+    assert o[0]["agent-3"]["other_agent_actions"].dtype == np.int64

@@ -1,6 +1,8 @@
 """Parity at BASELINE.json's full sizes (configs[1], configs[2]: 4096 envs x 5 agents on one GPU) and the
 size-independent properties the domain offers: shard invariance (configs[3]'s partitioning), determinism,
 wall / agent conservation, observation == re-render of the stored state."""
+import os
+
 import numpy as np
 import pytest
 
@@ -188,3 +190,104 @@ def test_step_observation_equals_observe_of_the_stored_state():
     assert (obs == again).all().item()
     unrot = eng.observe(rotate=False)
     assert not (unrot == again).all().item()
+
+
+def _rollout_vs_oracle(game, amap, E, N, seed, steps, step0, every, ring, chains, **kw):
+    """ssd_rollout_random on a fresh engine against the oracle stepped call by call: the last `ring` steps' observations and
+    rewards, and the final state."""
+    import torch
+    eng = VecEngine(game, amap, num_envs=E, num_agents=N, seed=seed)
+    ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), seed=seed)
+    eng.set_rollout_chains(chains)
+    obs = torch.zeros((ring, E, N, 15, 15, 3), dtype=torch.uint8, device="cuda")
+    rew = torch.zeros((ring, E, N), dtype=torch.int32, device="cuda")
+    done = torch.ones((ring, E, N), dtype=torch.uint8, device="cuda")
+    eng.reset()
+    ora.reset()
+    eng.rollout_random(steps, obs, rew, done, reset_every=every, step0=step0, **kw)
+    want = {}
+    for k in range(step0, step0 + steps):
+        if every and k % every == 0:
+            ora.reset()
+        _, o_obs, o_rew, _ = ora.step_random(want_obs=(k >= step0 + steps - ring))
+        want[k] = (o_obs, o_rew)
+    g_obs, g_rew = obs.cpu().numpy(), rew.cpu().numpy()
+    for k in range(step0 + steps - ring, step0 + steps):
+        np.testing.assert_array_equal(g_rew[k % ring], want[k][1], err_msg="rewards of step %d" % k)
+        assert np.array_equal(g_obs[k % ring], want[k][0]), "observations of step %d differ" % k
+    assert not done.any()
+    a, b = eng.get_state(), ora.get_state()
+    for key in ("world", "pos", "orient", "episode", "t"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert eng.status() == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("game", [K.GAME_HARVEST, K.GAME_CLEANUP])
+def test_the_exact_bench_path_at_full_size(game):
+    """What bench.py times, at its size: ssd_rollout_random over 4096 envs as 2 chains of 2048 (the library's own dispatch
+    queues), ring of one output slot, a full reset every 1000 steps -- 45 steps that cross step 1000 -- against the oracle."""
+    amap = K.HARVEST_MAP if game == K.GAME_HARVEST else K.CLEANUP_MAP
+    _rollout_vs_oracle(game, amap, 4096, 5, seed=0, steps=45, step0=975, every=1000, ring=1, chains=2)
+
+
+@pytest.mark.parametrize("mode", ["calls", "chains", "chains3", "fused", "pipelined"])
+@pytest.mark.parametrize("cfg", ["harvest25x38", "cleanup48x36"])
+def test_enlarged_maps_at_their_bench_sizes(cfg, mode):
+    """BASELINE.json's enlarged configurations at the sizes bench.py reports them: Harvest 25x38, 5 agents, 4096 envs (the
+    label of configs[1]) and Cleanup 48x36, 10 agents, 2048 envs (configs[4]'s per-GPU share: the LDS-tile stress -- the 64 KB
+    clamp of envs_per_block(), the 8 list registers, the pipelining capacity rule), 32 steps with a reset inside, stepped call
+    by call, as rollout chains, as the fused kernel and with pipelined launches where the library honours the request."""
+    import torch
+    if cfg == "harvest25x38":
+        game, amap, E, N = K.GAME_HARVEST, K.harvest_map_25x38(), 4096, 5
+    else:
+        game, amap, E, N = K.GAME_CLEANUP, K.cleanup_map_48x36(), 2048, 10
+    if mode == "calls":
+        eng = VecEngine(game, amap, num_envs=E, num_agents=N, seed=4)
+        ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), seed=4)
+        out = eng.alloc_outputs()
+        np.testing.assert_array_equal(eng.reset(obs=out[0]).cpu().numpy(), ora.reset())
+        for s in range(32):
+            if s == 20:
+                np.testing.assert_array_equal(eng.reset(obs=out[0]).cpu().numpy(), ora.reset())
+            obs, rew, done = eng.step_random(out=out)
+            _, o_obs, o_rew, _ = ora.step_random(want_obs=(s % 8 == 7 or s == 31))
+            np.testing.assert_array_equal(rew.cpu().numpy(), o_rew, err_msg="rewards, step %d" % s)
+            if s % 8 == 7 or s == 31:
+                assert np.array_equal(obs.cpu().numpy(), o_obs), "observations differ at step %d" % s
+        a, b = eng.get_state(), ora.get_state()
+        for k in ("world", "pos", "orient", "episode", "t"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        assert eng.status() == 0
+        return
+    kw = dict(fused=(mode == "fused"), pipelined=(mode == "pipelined"))
+    _rollout_vs_oracle(game, amap, E, N, seed=4, steps=32, step0=3, every=13, ring=2, chains={"chains3": 3}.get(mode, 2 if mode == "chains" else 1), **kw)
+
+
+def test_fuzz_slice_against_the_oracle():
+    """A deterministic slice of tools/fuzz_parity.py in the suite: random wall-closed maps (4x4 .. 25x30), 1-13 agents, views
+    1x1 .. 21x21, beams 1..8, 1-69 envs, with and without kept beams, each stepped call by call with random action subsets and
+    orders, as rollout chains (the library's own dispatch queues), as the fused rollout kernel and with SSD_AUTO_RESET -- all
+    against the oracle, bit for bit.  Fixed seed; as many configurations as fit in ~25 s (at least 40), every third one first so
+    that the slice spreads over the sequence.
+    Round 1's only kept fuzz record ended at `cfg 215: game 1 24x8 N=12 v=8 L=1 E=49 keep=1 seed=561232528 auto step 7`:
+    12 Cleanup shooters with beams of length 1 are up to 21 slots of one parallel trace, more than the 8 bits of the per-cell
+    slot mask that the then unfinished commit 5d01908 introduced (the commit capped the slots at 8; the log predates it by
+    three minutes).  The map of that run cannot be redrawn (the map generator changed since), so that configuration -- game,
+    shape, agents, view, beam length, envs, kept beams, engine seed -- is replayed on six maps of its shape."""
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import fuzz_parity
+    fuzz_parity.replay_cfg215(variants=6)
+    rng = np.random.RandomState(0)
+    cfgs = [fuzz_parity.draw(rng, i) for i in range(216)]
+    t0, n = time.time(), 0
+    for i in list(range(0, 216, 3)) + list(range(1, 216, 3)) + list(range(2, 216, 3)):
+        if n >= 40 and time.time() - t0 > 25.0:
+            break
+        fuzz_parity.run(cfgs[i], quiet=True)
+        n += 1
+    assert n >= 40

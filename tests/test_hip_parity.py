@@ -385,51 +385,63 @@ def test_limits_are_rejected_with_messages():
         assert needle in str(ei.value), str(ei.value)
 
 
+def _f32_of(u8):
+    """map_env.py:199 in float64, cast to the declared float32 observation space (harvest.py:39-40)."""
+    return ((u8.astype(np.float64) - 128.0) / 255.0).astype(np.float32)
+
+
 def test_float32_observation_mode_is_the_cast_of_the_reference_float64():
     """SSD_OBS_F32: the kernel writes float32((u8 - 128.0) / 255.0) -- the reference's float64 observation
-    (map_env.py:199) cast to its declared float32 space -- for step, reset and observe; bit-exact, ragged E."""
+    (map_env.py:199) cast to its declared float32 space -- for step, reset, masked reset and observe.  The expectation is
+    the ORACLE's uint8 observation pushed through that formula (not another HIP engine's output); bit-exact, ragged E."""
     import torch
     for game, E, N in ((K.GAME_HARVEST, 259, 5), (K.GAME_CLEANUP, 64, 10)):
+        amap = K.HARVEST_MAP if game == K.GAME_HARVEST else K.CLEANUP_MAP
         a = VecEngine(game, None, num_envs=E, num_agents=N, seed=8, keep_beams=True)
-        b = VecEngine(game, None, num_envs=E, num_agents=N, seed=8, keep_beams=True)
+        ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), seed=8)
         fa = a.alloc_outputs(float32=True)
-        ub = b.alloc_outputs()
-
-        def same(f32, u8):
-            want = ((u8.cpu().numpy().astype(np.float64) - 128.0) / 255.0).astype(np.float32)
-            assert np.array_equal(f32.cpu().numpy(), want)
-
-        a.reset(obs=fa[0]); b.reset(obs=ub[0])
-        same(fa[0], ub[0])
-        for _ in range(12):
-            a.step_random(out=fa); b.step_random(out=ub)
-            same(fa[0], ub[0])
-            assert torch.equal(fa[1], ub[1])
-        same(a.observe(rotate=False, obs=torch.empty_like(fa[0])), b.observe(rotate=False))
-        mask = torch.from_numpy((np.arange(E) % 2).astype(np.uint8)).cuda()
+        a.reset(obs=fa[0])
+        assert np.array_equal(fa[0].cpu().numpy(), _f32_of(ora.reset()))
+        for s in range(12):
+            a.step_random(out=fa)
+            _, o_obs, o_rew, _ = ora.step_random()
+            assert np.array_equal(fa[0].cpu().numpy(), _f32_of(o_obs)), "step %d" % s
+            np.testing.assert_array_equal(fa[1].cpu().numpy(), o_rew)
+        got = a.observe(rotate=False, obs=torch.empty_like(fa[0]))
+        assert np.array_equal(got.cpu().numpy(), _f32_of(ora.observe(rotate=False)))
+        got = a.observe(rotate=True, obs=torch.empty_like(fa[0]))
+        assert np.array_equal(got.cpu().numpy(), _f32_of(ora.observe(rotate=True)))
+        mask_np = (np.arange(E) % 2).astype(np.uint8)
+        mask = torch.from_numpy(mask_np).cuda()
         before = fa[0].clone()
-        a.reset(mask=mask, obs=fa[0]); b.reset(mask=mask, obs=ub[0])
-        same(fa[0][mask.bool()], ub[0][mask.bool()])
+        a.reset(mask=mask, obs=fa[0])
+        o_reset = ora.reset(mask_np)
+        assert np.array_equal(fa[0].cpu().numpy()[mask_np != 0], _f32_of(o_reset[mask_np != 0]))
         assert torch.equal(fa[0][~mask.bool()], before[~mask.bool()])          # rows of envs that were not reset stay
+        st, so = a.get_state(), ora.get_state()
+        for k in ("world", "pos", "orient", "episode", "t"):
+            np.testing.assert_array_equal(st[k], so[k], err_msg=k)
+        assert a.status() == 0
 
 
 @pytest.mark.parametrize("view_len", [0, 1, 2, 4, 9, 15])
 def test_float32_observations_of_other_view_sizes(view_len):
     """The float32 stores are laid out by float index (four consecutive floats of an agent's block per lane and store, so a
     store instruction covers contiguous memory): views whose V*V*3 is below one store (3, 27, 75 floats), around one or a
-    few (243, 1083) and the largest (31 x 31: 2883 floats, 12 stores per agent) against the uint8 observations."""
+    few (243, 1083) and the largest (31 x 31: 2883 floats, 12 stores per agent) against the oracle's observations."""
     rng = np.random.default_rng(100 + view_len)
     amap = _random_map(rng, 11, 13, K.GAME_CLEANUP, 8)
     E, N = 37, 6
     a = VecEngine(K.GAME_CLEANUP, amap, num_envs=E, num_agents=N, seed=3, view_len=view_len)
-    b = VecEngine(K.GAME_CLEANUP, amap, num_envs=E, num_agents=N, seed=3, view_len=view_len)
-    fa, ub = a.alloc_outputs(float32=True), b.alloc_outputs()
-    a.reset(obs=fa[0]); b.reset(obs=ub[0])
+    ora = pyoracle.Oracle(K.GAME_CLEANUP, amap, E, N, G.default_lut(), view_len=view_len, seed=3)
+    fa = a.alloc_outputs(float32=True)
+    a.reset(obs=fa[0])
+    assert np.array_equal(fa[0].cpu().numpy(), _f32_of(ora.reset()))
     for _ in range(8):
-        a.step_random(out=fa); b.step_random(out=ub)
-        want = ((ub[0].cpu().numpy().astype(np.float64) - 128.0) / 255.0).astype(np.float32)
-        assert np.array_equal(fa[0].cpu().numpy(), want)
-    assert a.status() == 0 and b.status() == 0
+        a.step_random(out=fa)
+        _, o_obs, _, _ = ora.step_random()
+        assert np.array_equal(fa[0].cpu().numpy(), _f32_of(o_obs))
+    assert a.status() == 0
 
 
 @pytest.mark.parametrize("fused", [False, True])

@@ -26,7 +26,10 @@ def check_state(eng, ora, where):
         assert np.array_equal(a[k], b[k]), "%s differs (%s)" % (k, where)
 
 
-def one(rng, idx):
+def draw(rng, idx, fixed=None):
+    """Everything random about configuration `idx`, drawn from `rng` in the order the tool has always consumed it (so that
+    configuration k of a seed is the same configuration in every version and can be drawn without running the ones before)."""
+    c = {"idx": idx}
     game = int(rng.randint(0, 2))
     big = os.environ.get("FUZZ_BIG") == "1"               # the limits of the ABI: 64 agents, 4096 cells, 31 x 31 views, beams of 21
     H, W = (int(rng.randint(4, 65)), int(rng.randint(4, 65))) if big else (int(rng.randint(4, 26)), int(rng.randint(4, 31)))
@@ -39,16 +42,19 @@ def one(rng, idx):
     amap = _random_map(rng, H, W, game, n_spawn=N + int(rng.randint(0, 4)))
     keep = bool(rng.randint(0, 2))
     seed = int(rng.randint(0, 2 ** 31))
-    tag = "cfg %d: game %d %dx%d N=%d v=%d L=%d E=%d keep=%d seed=%d" % (idx, game, H, W, N, v, L, E, keep, seed)
-    try:
-        eng = VecEngine(game, amap, num_envs=E, num_agents=N, view_len=v, beam_len=L, seed=seed, keep_beams=keep)
-    except Exception as ex:                                   # e.g. LDS budget: not a parity matter
-        print(tag, "-> skipped:", str(ex)[:80])
-        return
-    ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), view_len=v, beam_len=L, seed=seed)
-    V, na = 2 * v + 1, (8 if game == K.GAME_HARVEST else 9)
-    assert np.array_equal(eng.reset_host(), ora.reset()), tag + " reset"
-    # (1) call by call, explicit subsets / orders every other step
+    if fixed is not None:                                     # a recorded configuration on a freshly drawn map
+        game, H, W, N, v, L, E, keep, seed = fixed
+        amap = _random_map(rng, H, W, game, n_spawn=N + 2)
+    c.update(game=game, H=H, W=W, N=N, v=v, L=L, E=E, amap=amap, keep=keep, seed=seed)
+    c["tag"] = "cfg %d: game %d %dx%d N=%d v=%d L=%d E=%d keep=%d seed=%d" % (idx, game, H, W, N, v, L, E, keep, seed)
+    # the 64 KiB LDS rule of ssd_create (ssd_capi.hip): such a configuration is skipped before anything else is drawn
+    WP = W + v
+    S = (H * WP + 15) & ~15
+    c["too_big"] = 512 + 256 + 2048 + ((v * (WP + 1) + 15) & ~15) + ((v * WP + 15) & ~15) + 3 * S > 64 * 1024
+    if c["too_big"]:
+        return c
+    na = 8 if game == K.GAME_HARVEST else 9
+    c["steps"] = []
     for s in range(12):
         if s % 2:
             act = rng.randint(0, na, size=(E, N)).astype(np.int32)
@@ -58,6 +64,33 @@ def one(rng, idx):
                 perm = rng.permutation(N)[:k]
                 order[e, :k] = perm
                 act[e, np.setdiff1d(np.arange(N), perm)] = -1
+            c["steps"].append((act, order))
+        else:
+            c["steps"].append(None)
+    c["rollouts"] = [(int(rng.randint(1, 14)), int(rng.randint(1, 8)), int(rng.randint(1, 5))) for _ in range(2)]
+    c["horizon"] = int(rng.randint(2, 7))
+    c["part"] = (rng.rand(E) < 0.5).astype(np.uint8)
+    return c
+
+
+def run(c, quiet=False):
+    game, N, v, L, E, amap, keep, seed, tag = c["game"], c["N"], c["v"], c["L"], c["E"], c["amap"], c["keep"], c["seed"], c["tag"]
+    try:
+        eng = VecEngine(game, amap, num_envs=E, num_agents=N, view_len=v, beam_len=L, seed=seed, keep_beams=keep)
+    except Exception as ex:                                   # e.g. LDS budget: not a parity matter
+        if not c["too_big"]:
+            raise
+        if not quiet:
+            print(tag, "-> skipped:", str(ex)[:80])
+        return
+    assert not c["too_big"], tag
+    ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), view_len=v, beam_len=L, seed=seed)
+    V = 2 * v + 1
+    assert np.array_equal(eng.reset_host(), ora.reset()), tag + " reset"
+    # (1) call by call, explicit subsets / orders every other step
+    for s, inp in enumerate(c["steps"]):
+        if inp is not None:
+            act, order = inp
             obs, rew, _ = eng.step_host(act, order)
             o_obs, o_rew, _ = ora.step(act, order)
         else:
@@ -71,9 +104,8 @@ def one(rng, idx):
     rew = torch.zeros((ring, E, N), dtype=torch.int32, device="cuda")
     done = torch.zeros((ring, E, N), dtype=torch.uint8, device="cuda")
     step0 = 0
-    for fused in (False, True):
-        n, every = int(rng.randint(1, 14)), int(rng.randint(1, 8))
-        eng.set_rollout_chains(int(rng.randint(1, 5)))
+    for fused, (n, every, chains) in zip((False, True), c["rollouts"]):
+        eng.set_rollout_chains(chains)
         want = {}
         for k in range(step0, step0 + n):
             if k % every == 0:
@@ -88,10 +120,10 @@ def one(rng, idx):
         check_state(eng, ora, tag + " after rollout fused=%d" % fused)
         step0 += n
     # (4) auto-reset in the step launch, envs out of phase
-    Hz = int(rng.randint(2, 7))
+    Hz = c["horizon"]
     eng.set_horizon(Hz)
     out = eng.alloc_outputs()
-    part = (rng.rand(E) < 0.5).astype(np.uint8)
+    part = c["part"]
     eng.reset(mask=torch.from_numpy(part).cuda(), obs=out[0]); ora.reset(part)
     for s in range(9):
         o, r, d = eng.step_random(out=out, auto_reset=True)
@@ -105,6 +137,10 @@ def one(rng, idx):
     check_state(eng, ora, tag + " after auto-reset steps")
     assert eng.status() == 0, tag + " status"
     eng.close()
+
+
+def one(rng, idx, quiet=False, fixed=None):
+    run(draw(rng, idx, fixed), quiet)
 
 
 def main():
