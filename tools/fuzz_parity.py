@@ -143,6 +143,14 @@ def one(rng, idx, quiet=False, fixed=None):
     run(draw(rng, idx, fixed), quiet)
 
 
+def replay_cfg215(variants=12):
+    """Round 1's only kept fuzz record ended in a parity failure: `cfg 215: game 1 24x8 N=12 v=8 L=1 E=49 keep=1
+    seed=561232528 auto step 7` (Cleanup, 12 agents, beams of length 1, SSD_AUTO_RESET).  The map of that run was not kept, so
+    the configuration is replayed on `variants` random maps of that shape."""
+    for i in range(variants):
+        one(np.random.RandomState(215000 + i), 215, quiet=True, fixed=(1, 24, 8, 12, 8, 1, 49, True, 561232528))
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
