@@ -139,7 +139,7 @@ def time_rollout(torch, eng, ring, steps, warmup, step0=0, **kw):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     ev1.record()
-    wchunk = max(1, warmup // 4)
+    wchunk = max(4, warmup // 4)
     for w0 in range(0, warmup, wchunk):
         run(step0 + w0, min(wchunk, warmup - w0))
     torch.cuda.synchronize()
@@ -315,7 +315,7 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     # the W warm-up steps, issued as a few calls rather than one (every call exercises the whole enqueue path)
-    wchunk = max(1, args.warmup // 4)
+    wchunk = max(4, args.warmup // 4)
     for w0 in range(0, args.warmup, wchunk):
         run_steps(w0, min(wchunk, args.warmup - w0))
     torch.cuda.synchronize()

@@ -55,7 +55,7 @@ namespace {
     X(hsa_signal_store_relaxed) X(hsa_signal_load_relaxed) X(hsa_code_object_reader_create_from_memory)                    \
     X(hsa_code_object_reader_destroy) X(hsa_executable_create_alt) X(hsa_executable_load_agent_code_object)                \
     X(hsa_executable_freeze) X(hsa_executable_get_symbol_by_name) X(hsa_executable_symbol_get_info) X(hsa_status_string)           \
-    X(hsa_amd_queue_set_priority)
+    X(hsa_signal_wait_scacquire)
 
 struct Api {
 #define X(f) decltype(&::f) f = nullptr;
@@ -247,7 +247,8 @@ struct Queue {
     uint32_t *abort_flag = nullptr;             // host memory the waiting kernel looks at: set on a queue error
     void *flag_kernarg = nullptr;               // (host kernarg pool) the flag kernel's one argument: the join counter
     Kernel flag_kernel{};
-    hsa_signal_t done_signal{};                 // experiment (SSD_AQL_SIGNAL=1): completion signal attached to every dispatch
+    bool attach_signal = false;
+    hsa_signal_t done_signal{};                 // completion signal of the join packet in synchronous mode (join_and_wait)
 };
 
 static void queue_error_cb(hsa_status_t status, hsa_queue_t *, void *data) {
@@ -262,26 +263,20 @@ static void queue_error_cb(hsa_status_t status, hsa_queue_t *, void *data) {
 Queue *queue_create(int device, unsigned long long *join_counter, uint32_t *abort_flag) {
     DeviceCtx *c = device_ctx(device);
     if (!c) return nullptr;
-    static const int skip = [] { const char *v = getenv("SSD_AQL_SKIP_QUEUES"); return v ? atoi(v) : 0; }();   // experiment: spacer queues
-    for (int i = 0; i < skip; ++i) {
-        hsa_queue_t *dummy = nullptr;
-        g_api.hsa_queue_create(c->gpu, 64, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &dummy);   // (leaked on purpose)
-    }
     Queue *Q = new Queue();
     Q->ctx = c;
     static const uint32_t qsize = [] { const char *v = getenv("SSD_AQL_QUEUE_SIZE"); int n = v ? atoi(v) : 4096; return (uint32_t)(n >= 64 ? n : 4096); }();
     uint32_t size = 64;
     while (size < qsize) size <<= 1;
-    static const int qtype = [] { const char *v = getenv("SSD_AQL_QUEUE_MULTI"); return v && atoi(v) ? (int)HSA_QUEUE_TYPE_MULTI : (int)HSA_QUEUE_TYPE_SINGLE; }();   // tuning
-    if (g_api.hsa_queue_create(c->gpu, size, (hsa_queue_type32_t)qtype, queue_error_cb, Q, UINT32_MAX, UINT32_MAX, &Q->q) != HSA_STATUS_SUCCESS) {
+    // (a handle's total matters: with 4 queues of its own beside the HIP runtime's -- even idle ones -- every launch of the
+    // process slowed to ~30 us on this device, the hardware scheduler then time-slices its queue slots; 3 were fine: the
+    // library never creates more than one per chain and rollouts use 2)
+    if (g_api.hsa_queue_create(c->gpu, size, HSA_QUEUE_TYPE_SINGLE, queue_error_cb, Q, UINT32_MAX, UINT32_MAX, &Q->q) != HSA_STATUS_SUCCESS) {
         say("hsa_queue_create failed");
         delete Q;
         return nullptr;
     }
-    static const int prio = [] { const char *v = getenv("SSD_AQL_PRIORITY"); return v ? atoi(v) : -1; }();   // tuning: 0 low 1 normal 2 high
-    if (prio >= 0) g_api.hsa_amd_queue_set_priority(Q->q, (hsa_amd_queue_priority_t)prio);
-    static const bool with_signal = [] { const char *v = getenv("SSD_AQL_SIGNAL"); return v && atoi(v) != 0; }();
-    if (with_signal) g_api.hsa_signal_create(1ll << 60, 0, nullptr, &Q->done_signal);
+    if (g_api.hsa_signal_create(0, 0, nullptr, &Q->done_signal) != HSA_STATUS_SUCCESS) Q->done_signal.handle = 0;
     Q->mask = Q->q->size - 1;
     Q->widx = Q->rung = g_api.hsa_queue_load_read_index_scacquire(Q->q);
     Q->abort_flag = abort_flag;
@@ -301,6 +296,7 @@ Queue *queue_create(int device, unsigned long long *join_counter, uint32_t *abor
 void queue_destroy(Queue *Q) {
     if (!Q) return;
     if (Q->q) g_api.hsa_queue_destroy(Q->q);
+    if (Q->done_signal.handle) g_api.hsa_signal_destroy(Q->done_signal);
     if (Q->flag_kernarg) g_api.hsa_amd_memory_pool_free(Q->flag_kernarg);
     delete Q;
 }
@@ -338,7 +334,7 @@ void dispatch(Queue *Q, const Kernel &k, uint32_t grid_x, uint32_t block_x, uint
     pk->kernel_object = k.object;
     pk->kernarg_address = const_cast<void *>(kernarg_dev);
     pk->reserved2 = 0;
-    pk->completion_signal.handle = Q->done_signal.handle;
+    pk->completion_signal.handle = Q->attach_signal ? Q->done_signal.handle : 0;
     publish(pk, header_of(HSA_PACKET_TYPE_KERNEL_DISPATCH, barrier, acquire_scope, release_scope), 1 /* dimensions */);
     Q->widx++;
 }
@@ -366,6 +362,19 @@ uint64_t read_index(const Queue *Q) { return g_api.hsa_queue_load_read_index_sca
 void join(Queue *Q) {
     dispatch(Q, Q->flag_kernel, 1, 64, 0, Q->flag_kernarg, /*barrier=*/true, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM);
     ring(Q);
+}
+
+// Synchronous join (SSD_AQL_SYNC=1: profiling with serialised kernels, where a kernel that waits for another queue's kernel
+// would wait forever): the join packet carries a completion signal and the HOST waits for it.
+bool join_and_wait(Queue *Q) {
+    if (!Q->done_signal.handle) return false;
+    g_api.hsa_signal_store_screlease(Q->done_signal, 1);
+    Q->attach_signal = true;
+    join(Q);
+    Q->attach_signal = false;
+    while (g_api.hsa_signal_wait_scacquire(Q->done_signal, HSA_SIGNAL_CONDITION_LT, 1, 1000000, HSA_WAIT_STATE_BLOCKED) >= 1)
+        if (Q->error.load()) return false;
+    return true;
 }
 
 // FORK signals

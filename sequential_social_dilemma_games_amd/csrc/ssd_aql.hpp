@@ -25,6 +25,7 @@ void dispatch(Queue *q, const Kernel &k, uint32_t grid_x, uint32_t block_x, uint
               bool barrier, int acquire_scope, int release_scope);
 void barrier_and(Queue *q, uint64_t dep_signal_handle);      // the queue waits until the signal's value is 0
 void ring(Queue *q);                               // doorbell: hand everything written so far to the command processor
+bool join_and_wait(Queue *q);                      // synchronous form: the host waits until the join packet has completed
 void join(Queue *q);                               // after everything enqueued on q so far: join_counter += 1 (and a system-scope release)
 
 uint64_t signal_create(long long initial);         // 0 on failure

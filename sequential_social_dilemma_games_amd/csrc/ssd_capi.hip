@@ -67,22 +67,30 @@ struct AqlState {
     uint32_t *abort_flag = nullptr;                 // host memory (device-mapped): a queue reported an error
     struct Key {
         const void *obs = nullptr, *rew = nullptr, *done = nullptr;
-        int32_t ring = 0, f32 = 0, num_actions = 0, chains = 0, horizon = 0, coherent = 0;
+        int32_t ring = 0, f32 = 0, num_actions = 0, chains = 0, horizon = 0, coherent = 0, split = 0;
         bool operator==(const Key &o) const {
             return obs == o.obs && rew == o.rew && done == o.done && ring == o.ring && f32 == o.f32 && num_actions == o.num_actions &&
-                   chains == o.chains && horizon == o.horizon && coherent == o.coherent;
+                   chains == o.chains && horizon == o.horizon && coherent == o.coherent && split == o.split;
         }
     };
     struct Geo { ssd::aql::Kernel k; uint32_t grid_x = 0, block_x = 0, lds = 0; };
     struct Set {
         bool valid = false;
         Key key;
-        uint8_t *dev = nullptr;                     // [chains][ring][3] blocks of kBlock bytes: step, reset, step with the other geometry
+        uint8_t *dev = nullptr;                     // [chains][ring][kKinds] blocks of kBlock bytes
         size_t cap = 0;
-        Geo step[8], reset[8], alt[8];              // per chain (alt: test knob SSD_AQL_ALTERNATE)
+        Geo geo[8][10];                             // per chain and kind
         uint64_t last_use[8] = {};                  // index of the last join packet after a use, per chain (+1)
         uint64_t stamp = 0;
     };
+    // kinds of launches a rollout is made of: the step of an even / odd step number (they differ in the snapshot buffers of a
+    // split rollout, and in their geometry under the test knob SSD_AQL_ALTERNATE); the reset; and for split rollouts the step
+    // launch that also renders the step before (AB) and the launch that only renders (B: the last step's observations)
+    // (kS / kR: the launches of a rollout that is not split -- step with observations, reset with observations; kRn: the reset of
+    // a split rollout, which renders nothing)
+    enum Kind { kS0 = 0, kS1 = 1, kR = 2, kRn = 3, kA0 = 4, kA1 = 5, kAB0 = 6, kAB1 = 7, kB0 = 8, kB1 = 9, kKinds = 10 };
+    uint8_t *snap_grid[2] = {};                     // split rollouts: [E][S] overlay snapshots, by step parity
+    uint32_t *snap_agents[2] = {};                  // ... and [E][N] agents
     static constexpr int kSets = 4;
     static constexpr size_t kBlock = 512;           // >= sizeof(ssd::KernArgs), a multiple of 64
     Set sets[kSets];
@@ -705,6 +713,7 @@ static void aql_teardown(ssd_env *env) {
     if (A.join_counter) (void)hipFree(A.join_counter);
     if (A.abort_flag) (void)hipHostFree(A.abort_flag);
     for (auto &st : A.sets) if (st.dev) (void)hipFree(st.dev);
+    for (int i = 0; i < 2; ++i) { if (A.snap_grid[i]) (void)hipFree(A.snap_grid[i]); if (A.snap_agents[i]) (void)hipFree(A.snap_agents[i]); }
     env->aql.reset();
 }
 
@@ -761,7 +770,8 @@ static AqlState::Set *aql_set(ssd_env *env, const AqlState::Key &key, int chains
     AqlState::Set &st = *victim;
     if (st.valid) for (int c = 0; c < 8 && c < A.nq; ++c) aql_wait_consumed(A.q[c], st.last_use[c]);   // nobody reads the old blocks any more
     st.valid = false;
-    const size_t need = (size_t)chains * key.ring * 3 * AqlState::kBlock;
+    constexpr int kKinds = AqlState::kKinds;
+    const size_t need = (size_t)chains * key.ring * kKinds * AqlState::kBlock;
     if (need > st.cap) {
         if (st.dev) (void)hipFree(st.dev);
         st.dev = nullptr; st.cap = 0;
@@ -769,28 +779,61 @@ static AqlState::Set *aql_set(ssd_env *env, const AqlState::Key &key, int chains
         if (hipMalloc(&ptr, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         st.dev = static_cast<uint8_t *>(ptr); st.cap = need;
     }
+    if (key.split && !A.snap_grid[0]) {                 // the snapshot buffers of split rollouts, once per handle
+        for (int i = 0; i < 2; ++i) {
+            void *g = nullptr, *a = nullptr;
+            if (hipMalloc(&g, (size_t)env->E * env->S) != hipSuccess || hipMalloc(&a, (size_t)env->E * (env->N ? env->N : 1) * 4) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            A.snap_grid[i] = static_cast<uint8_t *>(g); A.snap_agents[i] = static_cast<uint32_t *>(a);
+        }
+    }
     std::vector<uint8_t> host(need, 0);
     for (int c = 0; c < chains; ++c) {
         ChainCursor cur = chain_cursor(env, jobs[c]);
         for (int r = 0; r < key.ring; ++r)
-            for (int kind = 0; kind < 3; ++kind) {
-                if (kind == 2 && key.coherent != 2) continue;
+            for (int kind = 0; kind < kKinds; ++kind) {
+                const bool only_b = kind == AqlState::kB0 || kind == AqlState::kB1;
+                const bool with_b = only_b || kind == AqlState::kAB0 || kind == AqlState::kAB1;
+                const bool split_kind = kind >= AqlState::kRn;
+                if (split_kind && !key.split) continue;
+                // parity of the step the launch COMPUTES (kB: of the step it renders)
+                const int parity = (kind == AqlState::kS1 || kind == AqlState::kA1 || kind == AqlState::kAB1 || kind == AqlState::kB1) ? 1 : 0;
                 Params p = cur.p;
                 p.obs = cur.obs ? cur.obs + (size_t)r * cur.ob : nullptr;
-                p.coherent = key.coherent ? (kind == 2 ? 2u : 1u) : 0u;
-                if (kind == 1) { p.mode = ssd::kModeReset; p.rotate = 0; p.num_actions_random = 0; p.rew = nullptr; p.done = nullptr; }
-                else {
+                // (test knob: odd steps' launches use the other geometry)
+                p.coherent = key.coherent ? ((key.coherent == 2 && parity == 1) ? 2u : 1u) : 0u;
+                if (kind == AqlState::kR || kind == AqlState::kRn) {
+                    p.mode = ssd::kModeReset; p.rotate = 0; p.num_actions_random = 0; p.rew = nullptr; p.done = nullptr;
+                    // (every reset of a rollout is followed by a step that writes the same observation slot)
+                    if (kind == AqlState::kRn) p.obs = nullptr;
+                } else {
                     p.mode = ssd::kModeStep; p.rotate = 1; p.num_actions_random = cur.num_actions;
                     p.rew = cur.rew ? cur.rew + (size_t)r * cur.en : nullptr; p.done = cur.done ? cur.done + (size_t)r * cur.en : nullptr;
+                    if (split_kind) {
+                        // the envs' waves leave a snapshot in buffer `parity`; the renderer workgroups of an AB launch render the
+                        // step before (the other buffer) into the ring slot before this one, those of a B launch this step's
+                        uint8_t *obs_r = p.obs;
+                        uint8_t *obs_prev = cur.obs ? cur.obs + (size_t)((r + key.ring - 1) % key.ring) * cur.ob : nullptr;
+                        p.obs = nullptr;
+                        p.snap_mode = 1; p.snap = A.snap_grid[parity]; p.snap_agents = A.snap_agents[parity];
+                        if (with_b) {
+                            const int src = only_b ? parity : 1 - parity;
+                            p.snap_mode = only_b ? (2 | 4) : (1 | 2);
+                            p.snap_in = A.snap_grid[src]; p.snap_in_agents = A.snap_agents[src];
+                            p.obs_b = only_b ? obs_r : obs_prev;
+                        }
+                    }
                 }
                 ssd::Launch L;
                 if (!ssd::select(p, env->game, &L)) return nullptr;
-                AqlState::Geo &g = kind == 1 ? st.reset[c] : kind == 2 ? st.alt[c] : st.step[c];
+                AqlState::Geo &g = st.geo[c][kind];
                 if (r == 0) {
                     if (!ssd::aql::lookup(env->device, L.fn, &g.k) || g.k.kernarg_size > AqlState::kBlock || g.k.kernarg_size < sizeof(ssd::KernArgs)) return nullptr;
                     g.grid_x = L.grid_x; g.block_x = L.block_x; g.lds = L.lds;
                 }
-                std::memcpy(host.data() + (((size_t)c * key.ring + r) * 3 + kind) * AqlState::kBlock, &L.args, sizeof(ssd::KernArgs));
+                std::memcpy(host.data() + (((size_t)c * key.ring + r) * kKinds + kind) * AqlState::kBlock, &L.args, sizeof(ssd::KernArgs));
             }
     }
     if (hipMemcpy(st.dev, host.data(), need, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -811,20 +854,43 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     // Coherent chains: with a map-specific uint8 kernel (and its write-through observation stores: up to 16 384 envs per launch)
     // state and outputs move with agent-scope accesses only, so the step packets need no release fence (ssd_kernels.hip, PIPE = 2).
     // SSD_AQL_COHERENT=0 keeps the plain kernels with agent-scope acquire + release on every packet; SSD_AQL_ALTERNATE=1 (test)
-    // makes every other step launch use half the envs per workgroup -- an env then changes workgroup, and with it XCD and L2, from
-    // one step to the next.
+    // makes every other launch use half the envs per workgroup -- an env then changes workgroup, and with it XCD and L2, from
+    // one launch to the next that touches it.
     static const int env_coh = [] { const char *v = getenv("SSD_AQL_COHERENT"); return v ? atoi(v) : 1; }();
     static const bool alternate = [] { const char *v = getenv("SSD_AQL_ALTERNATE"); return v && atoi(v) != 0; }();
     const bool coherent = env_coh != 0 && !key.f32 && ssd::fast_profile(env->p, env->game) > 0 && (env->E + chains - 1) / chains <= 16384;
     key.coherent = coherent ? (alternate ? 2 : 1) : 0;
-    if ((size_t)chains * j0.ring > 4096) return 1;                     // (argument blocks: 2 x 512 B per chain and slot)
+    // Split rollouts (coherent chains with observations, 4 steps or more): the wave that steps an env does not render its
+    // observations -- it leaves a snapshot of the overlay -- and the NEXT step's launch carries a second set of workgroups that
+    // render them while that step is being computed; a last launch of renderer workgroups alone delivers the last step's.  Still
+    // one launch per step and env range (+ 1 per call), every step's observations in its ring slot when the call's work is done;
+    // but the observation phase (1.2 of 5.7 us) is off the chain of dependent launches.  Snapshots alternate between two buffers
+    // (launch k reads the one launch k - 1 wrote and writes the other).  (Two launches per step in one queue -- step, then an
+    // observe launch beside the next step -- do not work: kernels of one queue run one after the other on this device even
+    // without the barrier bit: two chains' launches in ONE queue take 10.6 us per step, in two queues 5.8.)  SSD_AQL_SPLIT=0 turns it off.
+    static const int env_split = [] { const char *v = getenv("SSD_AQL_SPLIT"); return v ? atoi(v) : 1; }();
+    key.split = (coherent && env_split != 0 && j0.obs != nullptr) ? 1 : 0;   // (the argument set holds both forms' launches)
+    const bool split = key.split && j0.n_steps >= 4;
+    if ((size_t)chains * j0.ring > 2048) return 1;                     // (argument blocks: 10 x 512 B per chain and slot)
     AqlState::Set *st = aql_set(env, key, chains, jobs);
     if (!st) return 1;
     if (j0.n_steps == 0) return SSD_OK;
     // FORK: the chains wait (barrier-AND) for a signal that a one-wave kernel on the caller's stream zeroes -- unless the
     // stream has nothing pending, in which case there is nothing to wait for and the first step can start at once
     static const bool always_fork = [] { const char *v = getenv("SSD_AQL_ALWAYS_FORK"); return v && atoi(v) != 0; }();
-    const bool stream_idle = !always_fork && hipStreamQuery(s) == hipSuccess;
+    // SSD_AQL_SYNC=1: the call itself waits -- for the stream before, for the chains after -- and no kernel waits for another
+    // queue's kernel.  For tools that serialise kernels (rocprofv3 --pmc): there the waiting kernel of the join would spin forever.
+    static const bool sync_mode = [] { const char *v = getenv("SSD_AQL_SYNC"); return v && atoi(v) != 0; }();
+    if (sync_mode) SSD_HIP(env, hipStreamSynchronize(s));
+    bool stream_idle = sync_mode || (!always_fork && hipStreamQuery(s) == hipSuccess);
+    if (!stream_idle && !always_fork) {
+        // a marker or an event record just ahead of the call drains within microseconds: look again for a moment before paying
+        // for a fork (a kernel launch on the stream + a barrier packet that polls its signal: ~20 us until the first step starts)
+        static const int spin_us = [] { const char *v = getenv("SSD_AQL_FORK_SPIN_US"); return v ? atoi(v) : 8; }();
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!stream_idle && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us))
+            stream_idle = hipStreamQuery(s) == hipSuccess;
+    }
     if (!stream_idle) {
         (void)hipGetLastError();                                       // (hipErrorNotReady is not an error here)
         const int slot = A.fork_next;
@@ -838,30 +904,45 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
             A.fork_used[slot][c] = ssd::aql::write_index(A.q[c]);     // (= index of the barrier packet + 1)
         }
     }
-    // fence scopes of the step packets (hsa_fence_scope_t: 0 none, 1 agent, 2 system) and their barrier bit; the SSD_AQL_*
-    // variables are tuning knobs -- anything weaker than agent / agent / 1 gives up the ordering a HIP stream provides
+    // fence scopes of the step packets (hsa_fence_scope_t: 0 none, 1 agent, 2 system); the SSD_AQL_* variables are tuning
+    // knobs -- for the plain kernels anything weaker than agent / agent gives up the visibility a HIP stream provides
     static const int env_acq = [] { const char *v = getenv("SSD_AQL_ACQ"); return v ? atoi(v) : -1; }();
     static const int env_rel = [] { const char *v = getenv("SSD_AQL_REL"); return v ? atoi(v) : -1; }();
-    const int kAcq = env_acq >= 0 ? env_acq : 1, kRel = env_rel >= 0 ? env_rel : (coherent ? 0 : 1);
-    static const bool kBar = [] { const char *v = getenv("SSD_AQL_BARRIER"); return v ? atoi(v) != 0 : true; }();
+    // Coherent chains: only the first packet of the call acquires (what the caller's stream did before -- a set_state, another
+    // kernel -- may sit in caches); between the chain's own launches nothing is read through a cache that could be stale
+    // (-0.14 us per step).  The observe launches of a split rollout do acquire: they only READ their snapshot, so an L2 may
+    // still hold the lines as they were two steps ago.
+    const int kAcq = env_acq >= 0 ? env_acq : (coherent ? 0 : 1), kRel = env_rel >= 0 ? env_rel : (coherent ? 0 : 1);
     const int32_t ring = j0.ring, reset_every = j0.reset_every, step0 = j0.step0;
+    constexpr int kKinds = AqlState::kKinds;
+    auto put = [&](int c, size_t r, int kind, bool barrier, int acq, int rel) {
+        const AqlState::Geo &g = st->geo[c][kind];
+        ssd::aql::dispatch(A.q[c], g.k, g.grid_x, g.block_x, g.lds, st->dev + (((size_t)c * ring + r) * kKinds + kind) * AqlState::kBlock,
+                           barrier, acq, rel);
+    };
     for (int k = 0; k < j0.n_steps; ++k) {
         const size_t r = (size_t)((step0 + k) % ring);
+        const int parity = (step0 + k) & 1;
         const bool reset = reset_every > 0 && (step0 + k) % reset_every == 0;
         for (int c = 0; c < chains; ++c) {
-            const uint8_t *blocks = st->dev + (((size_t)c * ring + r) * 3) * AqlState::kBlock;
-            if (reset) {
-                const AqlState::Geo &g = st->reset[c];
-                ssd::aql::dispatch(A.q[c], g.k, g.grid_x, g.block_x, g.lds, blocks + AqlState::kBlock, true, 1, kRel);
-            }
-            const bool other = key.coherent == 2 && ((step0 + k) & 1);
-            const AqlState::Geo &g = other ? st->alt[c] : st->step[c];
-            ssd::aql::dispatch(A.q[c], g.k, g.grid_x, g.block_x, g.lds, blocks + (other ? 2 * AqlState::kBlock : 0), kBar, kAcq, kRel);
+            const int acq = k == 0 ? 1 : kAcq;                                 // (the call's first launch of the chain)
+            if (reset) put(c, r, split ? AqlState::kRn : AqlState::kR, true, acq, kRel);
+            const int kind = !split ? (parity ? AqlState::kS1 : AqlState::kS0)
+                                    : k > 0 ? (parity ? AqlState::kAB1 : AqlState::kAB0) : (parity ? AqlState::kA1 : AqlState::kA0);
+            put(c, r, kind, true, reset ? kAcq : acq, kRel);
+            if (split && k == j0.n_steps - 1) put(c, r, parity ? AqlState::kB1 : AqlState::kB0, true, kAcq, kRel);
             ssd::aql::ring(A.q[c]);
         }
     }
-    // JOIN: the caller's stream continues after every chain
     // JOIN: every chain ends by bumping the join counter; a one-wave kernel on the caller's stream sleeps until all have
+    if (sync_mode) {
+        bool ok = true;
+        for (int c = 0; c < chains; ++c) ssd::aql::ring(A.q[c]);
+        for (int c = 0; c < chains; ++c) { ok = ssd::aql::join_and_wait(A.q[c]) && ok; st->last_use[c] = ssd::aql::write_index(A.q[c]); }
+        A.joins += (unsigned long long)chains;
+        if (!ok) { env->err = "the HSA runtime reported an error on a dispatch queue"; A.ok = false; return SSD_E_DEVICE; }
+        return SSD_OK;
+    }
     for (int c = 0; c < chains; ++c) {
         ssd::aql::join(A.q[c]);
         st->last_use[c] = ssd::aql::write_index(A.q[c]);

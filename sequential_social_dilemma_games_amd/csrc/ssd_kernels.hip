@@ -146,6 +146,72 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
     uint32_t m = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
     return (m >> 7) * 0xFFu;
 }
+// The observation phase of the reference configuration (view_len 7: V = 15) for NA agents, five per pass: lane = 4 consecutive
+// cells of the 15 x 15 view = one 12-byte store (the lane holding the leftover 225th cell starts 4 cells before the end and
+// re-renders 3 cells of its neighbour, so that every store is a full 12 bytes).  All grid reads of a pass go out together, then
+// all colour-table reads, then the stores: two LDS round trips per pass.  `a_k` / `a_s0` hold, in lane = agent, the agent's
+// quarter turns and the LDS offset of its window's first (k < 2) or last (k >= 2) cell; `view_lds` is the LDS byte address of grid
+// cell 0 of the layer the views show.  (agent.py:76-78 -> utility_funcs.py:59-114, map_env.py:316-339, :669-689.)
+template <int NA>
+__device__ __forceinline__ void render_views_std(const int lane, const int WP, const uint32_t a_k, const uint32_t a_s0, const uint32_t view_lds,
+                                                 const uint32_t *s_lut, uint8_t *out_env, const bool wt) {
+    typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+    constexpr int V = 15, VV = 225, kB = 5;
+    const int pp_raw = 4 * lane;
+    const bool lane_on = pp_raw < VV;
+    const int pp0 = pp_raw > VV - 4 ? VV - 4 : pp_raw;                  // lanes past the end repeat the last one
+    int L0[4], L1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int pp = pp0 + q;
+        const int i = pp / 15, j = pp - i * V;
+        // 24-bit multiply-adds (full rate; a plain `*` becomes a quarter-rate 32-bit multiply here)
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(L0[q]) : "v"(i), "s"(WP), "v"(j));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(L1[q]) : "v"(j), "s"(WP), "v"(V - 1 - i));
+    }
+    uint32_t off3 = (uint32_t)pp0 * 3u;                                 // byte offset of the lane's cells in an agent's block
+    asm volatile("" : "+v"(off3));                                      // keep it in a register (else re-derived per agent)
+    for (int ag0 = 0; ag0 < NA; ag0 += kB) {
+        uint32_t addr[kB][4], px[kB][4];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+            const uint32_t k = rl(a_k, ag0 + u);
+            const uint32_t s0 = rl(a_s0, ag0 + u) + view_lds;
+            const int sgn = k >= 2 ? -1 : 1;
+            // wave-uniform branch on the rotation's parity instead of a per-cell select (the asm is volatile so that the two
+            // arms are not merged back into selects)
+            if (k & 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[u][q]) : "v"(L1[q]), "v"(sgn), "s"(s0));
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[u][q]) : "v"(L0[q]), "v"(sgn), "s"(s0));
+            }
+        }
+        uint32_t gl[kB][4];
+#pragma unroll
+        for (int u = 0; u < kB; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gl[u][q] = *(lds_u8 *)(uintptr_t)addr[u][q];
+#pragma unroll
+        for (int u = 0; u < kB; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) px[u][q] = s_lut[gl[u][q]];
+        if (lane_on) {
+#pragma unroll
+            for (int u = 0; u < kB; ++u) {
+                u32x3_t d;
+                // 4 x (r,g,b) -> 12 bytes with three byte permutes (v_perm_b32: selector bytes 0-3 pick from the second
+                // operand, 4-7 from the first)
+                d.x = __builtin_amdgcn_perm(px[u][1], px[u][0], 0x04020100u);   // r0 g0 b0 r1
+                d.y = __builtin_amdgcn_perm(px[u][2], px[u][1], 0x05040201u);   // g1 b1 r2 g2
+                d.z = __builtin_amdgcn_perm(px[u][3], px[u][2], 0x06050402u);   // b2 r3 g3 b3
+                store12_wt(out_env + (size_t)(ag0 + u) * VV * 3, off3, d, wt);
+            }
+        }
+    }
+}
+
 // Per-phase cycle stamps for tools/phase_profile.py: compiled only into the diagnostic library
 // (make stamps); the product build contains no stamp code.
 #ifdef SSD_STAMPS
@@ -192,6 +258,10 @@ __host__ size_t lds_bytes(const Params &p, int envs_per_block, bool f32) {
 // E=8192: 21.9 / 22.0 / 21.7 / 22.8;  E=65536: 111 / 113 / 117 / 136.  So: big blocks while the whole batch is one
 // round with at most one block per CU (256 CUs), small blocks once CUs run several rounds, and never fewer than
 // 256 blocks when the batch is small.  SSD_ENVS_PER_BLOCK overrides (tuning).
+static int forced_epb_early() {
+    static const int forced = [] { const char *v = getenv("SSD_ENVS_PER_BLOCK"); return v ? atoi(v) : 0; }();
+    return forced;
+}
 __host__ int envs_per_block(const Params &p, bool f32) {
     const int E = p.E - p.e_begin;
     static const int forced = [] { const char *v = getenv("SSD_ENVS_PER_BLOCK"); return v ? atoi(v) : 0; }();
@@ -277,6 +347,43 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     constexpr bool kFlag = PIPE == 1;                                // ... and ordered env by env through pass counters
     int blk = blockIdx.x;
     if constexpr (kFlag) blk = (int)((blockIdx.x + p.pipe_seq * p.pipe_rotate) % gridDim.x);   // (test knob; 0 = identity)
+    // ---- renderer role (split rollouts): workgroups behind the launch's first p.blocks_a render the observations of the
+    //      PREVIOUS step of their envs from the snapshot that step's wave left (p.snap_in), nothing else ----
+    if constexpr (MODE == kModeStep && PIPE == 2 && STD && NA > 0 && NA % 5 == 0 && !F32 && FAST != 0) {
+        if ((p.snap_mode & 2) && blk >= p.blocks_a) {
+            const int eb = a_e_begin + (blk - p.blocks_a) * a_epb + wv;
+            if (eb < a_E) {
+                const uint32_t lut_a = a_lut[lane], lut_b = a_lut[lane + 64];
+                u32x4_t g0 = {0u, 0u, 0u, 0u};
+                const uint8_t *gsrc = p.snap_in + (size_t)eb * S;
+                if (lane * 16 < S) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g0) : "v"(gsrc + lane * 16) : "memory");
+                uint32_t areg = 0;
+                if (lane < N) areg = __hip_atomic_load(p.snap_in_agents + (size_t)eb * N + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                {   // the aprons of the layer: '0' (void) cells
+                    const uint4 z = make_uint4(0x30303030u, 0x30303030u, 0x30303030u, 0x30303030u);
+                    const int n0 = A0 >> 4, n1 = A1 >> 4;
+                    for (int i = lane; i < n0 + n1; i += 64)
+                        *reinterpret_cast<uint4 *>(i < n0 ? s_world - A0 + i * 16 : s_world + S + (i - n0) * 16) = z;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0) : : "memory");
+                s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b;
+                if (lane * 16 < S) *reinterpret_cast<uint4 *>(s_world + lane * 16) = make_uint4(g0.x, g0.y, g0.z, g0.w);
+                for (int i = lane * 16 + 1024; i < S; i += 1024) {
+                    u32x4_t gv;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(gv) : "v"(gsrc + i) : "memory");
+                    *reinterpret_cast<uint4 *>(s_world + i) = make_uint4(gv.x, gv.y, gv.z, gv.w);
+                }
+                wave_sync();
+                typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+                const uint32_t cellb = areg & 0xFFFFu, orientb = (areg >> 16) & 3u;
+                const uint32_t kq = orientb == 2 ? 0u : orientb == 0 ? 1u : orientb == 3 ? 2u : 3u;     // rotate_view: UP 0, LEFT 1, DOWN 2, RIGHT 3
+                const uint32_t s0 = (uint32_t)((int)cellb - 7 * (WP + 1) + (kq >= 2 ? 14 * (WP + 1) : 0));
+                render_views_std<NA>(lane, WP, kq, s0, (uint32_t)(uintptr_t)(lds_u8 *)s_world, s_lut, p.obs_b + (size_t)eb * N * 675, true);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            return;
+        }
+    }
     const int e = a_e_begin + blk * a_epb + wv;             // (a_epb = blockDim.x / 64, without the implicit-argument load)
     constexpr int mode = MODE;                               // compile-time: step / reset / observe
     bool active = e < a_E;                                   // wave-uniform
@@ -1106,6 +1213,21 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 *reinterpret_cast<uint32_t *>(s_view + i) = v;
             }
             wave_sync();
+            // Split rollouts (ssd_capi.hip): the env's wave does not render observations; it leaves the overlay it has just
+            // built -- world <- agents <- beams -- and the agents' cells and rotations in a snapshot (write-through), and extra
+            // waves of the NEXT step's launch render from it (the renderer role below) while that step is being computed.  The
+            // observation phase (1.2 us of a 5.7 us step) thereby leaves the chain of dependent launches.
+            if constexpr (stepping && PIPE == 2) {
+                if ((p.snap_mode & 1) && is_step) {
+                    uint8_t *sg = p.snap + (size_t)e * S;
+                    for (int i = lane * 16; i < S; i += 64 * 16) {
+                        const uint4 v4 = *reinterpret_cast<const uint4 *>(s_view + i);
+                        const u32x4_t v = {v4.x, v4.y, v4.z, v4.w};
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(sg + i), "v"(v) : "memory");
+                    }
+                    if (is_agent) __hip_atomic_store(p.snap_agents + (size_t)e * N + lane, cell | (orient << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             SSD_STAMP(7);   // overlay built
             SSD_STAMP(8);
 
@@ -1178,6 +1300,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                             if (on) store16_wt(base_env + (size_t)ag * nf, (uint32_t)f0 * 4u, o, p.obs_wt != 0);
                         }
                     }
+                } else if constexpr (STD && NA > 0 && NA % 5 == 0 && !F32) {
+                    // Specialised kernels: five agents per pass (render_views_std)
+                    render_views_std<NA>(lane, WP, a_k, a_s0, world_lds, s_lut, out_env, p.obs_wt != 0);
                 } else
                 for (int base = 0; base < VV; base += 256) {
                     // A lane renders 4 consecutive cells = one 12-byte store.  V*V is not a multiple of 4 (225 = 56*4 + 1):
@@ -1199,46 +1324,6 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     uint32_t off3 = (uint32_t)pp0 * 3u;                                 // byte offset of the lane's cells in an agent's block
                     asm volatile("" : "+v"(off3));                                      // keep it in a register (else re-derived per agent)
                     const int ncell = lane_on ? VV - pp0 : 0;                           // >= 4 whenever VV >= 4
-                    if (STD && NA > 0 && NA % 5 == 0 && !F32) {
-                        // Specialised kernels: five agents per pass.  All their grid reads go out together, then all the
-                        // colour-table reads, then the stores: two LDS round trips per pass instead of two per agent.
-                        constexpr int kB = 5;
-                        for (int ag0 = 0; ag0 < NA; ag0 += kB) {
-                            uint32_t addr[kB][4], px[kB][4];
-#pragma unroll
-                            for (int u = 0; u < kB; ++u) {
-                                const uint32_t k = rl(a_k, ag0 + u);
-                                const uint32_t s0 = rl(a_s0, ag0 + u) + world_lds;
-                                const int sgn = k >= 2 ? -1 : 1;
-                                if (k & 1) {
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[u][q]) : "v"(L1[q]), "v"(sgn), "s"(s0));
-                                } else {
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q) asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr[u][q]) : "v"(L0[q]), "v"(sgn), "s"(s0));
-                                }
-                            }
-                            uint32_t gl[kB][4];
-#pragma unroll
-                            for (int u = 0; u < kB; ++u)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) gl[u][q] = *(lds_u8 *)(uintptr_t)addr[u][q];
-#pragma unroll
-                            for (int u = 0; u < kB; ++u)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) px[u][q] = s_lut[gl[u][q]];
-                            if (lane_on) {
-#pragma unroll
-                                for (int u = 0; u < kB; ++u) {
-                                    u32x3_t d;
-                                    d.x = __builtin_amdgcn_perm(px[u][1], px[u][0], 0x04020100u);   // r0 g0 b0 r1
-                                    d.y = __builtin_amdgcn_perm(px[u][2], px[u][1], 0x05040201u);   // g1 b1 r2 g2
-                                    d.z = __builtin_amdgcn_perm(px[u][3], px[u][2], 0x06050402u);   // b2 r3 g3 b3
-                                    store12_wt(out_env + (size_t)(ag0 + u) * VV * 3, off3, d, p.obs_wt != 0);
-                                }
-                            }
-                        }
-                    } else
                     for (int ag = 0; ag < N; ++ag) {
                         const uint32_t k = rl(a_k, ag);
                         const uint32_t s0 = rl(a_s0, ag) + world_lds;
@@ -1323,7 +1408,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         }
         if (roll) write_state();
         // (the launch that follows in the chain starts when this one has ended: every store of this wave has landed by then)
+#ifndef SSD_EXP_NO_END_WAIT
         if constexpr (PIPE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     }
     SSD_STAMP(9);       // observations issued
     SSD_STAMP_RT(11);
@@ -1422,12 +1509,18 @@ bool select(const Params &p_in, int game, Launch *out) {
     static const int forced_epb = [] { const char *v = getenv("SSD_ENVS_PER_BLOCK"); return v ? atoi(v) : 0; }();
     const bool f32 = p.obs && p.obs_f32;            // the float32-observation variant is a separate instantiation
     int epb = envs_per_block(p, f32);
+    static const int split_epb = [] { const char *v = getenv("SSD_SPLIT_EPB"); return v ? atoi(v) : 4; }();   // tuning
+    // split rollouts run twice the waves per launch: smaller workgroups (measured: 4 envs per workgroup 5.23, 8: 5.78 us per step)
+    if (p.snap_mode && forced_epb_early() <= 0 && epb > split_epb && split_epb >= 1) epb = split_epb;
+    // (raising the issue priority of the env waves over the renderer waves changes nothing: 5.23 - 5.36 us)
     // test knob of the coherent chains (ssd_capi.hip, SSD_AQL_ALTERNATE): half the envs per workgroup, i.e. another env ->
     // workgroup -> XCD mapping than the launches before and after
     if (p.coherent == 2 && epb > 1 && forced_epb <= 0) epb /= 2;
-    static const bool plain_exp = [] { const char *v = getenv("SSD_TEST_ALT_PLAIN"); return v && atoi(v) != 0; }();   // experiment
-    if (plain_exp) p.coherent = 0;
     out->grid_x = (uint32_t)((p.E - p.e_begin + epb - 1) / epb);
+    if (p.snap_mode & 2) {                          // renderer workgroups behind the env workgroups (4: no env workgroups at all)
+        p.blocks_a = (p.snap_mode & 4) ? 0 : (int32_t)out->grid_x;
+        out->grid_x = (uint32_t)p.blocks_a + out->grid_x;
+    }
     out->block_x = (uint32_t)(64 * epb);
     out->lds = (uint32_t)lds_bytes(p, epb, f32);
     if (game == 0) out->fn = f32 ? select_game<0, true>(p) : select_game<0, false>(p);
