@@ -858,7 +858,11 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     // one launch to the next that touches it.
     static const int env_coh = [] { const char *v = getenv("SSD_AQL_COHERENT"); return v ? atoi(v) : 1; }();
     static const bool alternate = [] { const char *v = getenv("SSD_AQL_ALTERNATE"); return v && atoi(v) != 0; }();
-    const bool coherent = env_coh != 0 && !key.f32 && ssd::fast_profile(env->p, env->game) > 0 && (env->E + chains - 1) / chains <= 16384;
+    // (measured, us per step: 2048 envs per launch 5.5 split / 5.9 coherent / 6.2 plain; 2730: 9.7 / 8.6 / 8.7; 5461: 19.1 / 15.2 /
+    // 14.3 -- once a launch is several rounds of waves the kernel is bandwidth-bound, and re-reading state from an L2 that still
+    // holds it beats fetching it from memory: coherent chains up to 4096 envs per launch, split ones up to 2304)
+    const int per_launch = (env->E + chains - 1) / chains;
+    const bool coherent = env_coh != 0 && !key.f32 && ssd::fast_profile(env->p, env->game) > 0 && per_launch <= 4096;
     key.coherent = coherent ? (alternate ? 2 : 1) : 0;
     // Split rollouts (coherent chains with observations, 4 steps or more): the wave that steps an env does not render its
     // observations -- it leaves a snapshot of the overlay -- and the NEXT step's launch carries a second set of workgroups that
@@ -869,7 +873,7 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     // observe launch beside the next step -- do not work: kernels of one queue run one after the other on this device even
     // without the barrier bit: two chains' launches in ONE queue take 10.6 us per step, in two queues 5.8.)  SSD_AQL_SPLIT=0 turns it off.
     static const int env_split = [] { const char *v = getenv("SSD_AQL_SPLIT"); return v ? atoi(v) : 1; }();
-    key.split = (coherent && env_split != 0 && j0.obs != nullptr) ? 1 : 0;   // (the argument set holds both forms' launches)
+    key.split = (coherent && env_split != 0 && j0.obs != nullptr && per_launch <= 2304) ? 1 : 0;   // (the argument set holds both forms' launches)
     const bool split = key.split && j0.n_steps >= 4;
     if ((size_t)chains * j0.ring > 2048) return 1;                     // (argument blocks: 10 x 512 B per chain and slot)
     AqlState::Set *st = aql_set(env, key, chains, jobs);

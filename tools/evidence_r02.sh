@@ -1,0 +1,15 @@
+#!/bin/bash
+# tools/evidence_r02.sh -- run ON THE GPU BOX: the long parity runs of the final build whose logs are kept under profiles/:
+# the fuzz tool (400 random configurations through every API path) and the soak (4096 envs x 5000 steps per game as rollout
+# chains -- the library's own dispatch queues, coherent, split -- and with SSD_AQL_ALTERNATE=1, which moves every env to another
+# workgroup / XCD from one launch to the next).
+cd $GRAFT_REPO_ROOT
+D=gpurun_out/r02_evidence
+mkdir -p $D
+python3 tools/fuzz_parity.py 400 0 2>&1 | grep -v amdgpu.ids | tee $D/fuzz_400_seed0.log | tail -3
+FUZZ_BIG=1 python3 tools/fuzz_parity.py 100 7 2>&1 | grep -v amdgpu.ids | tee $D/fuzz_big_100_seed7.log | tail -2
+for g in harvest cleanup; do
+  python3 tools/soak_parity.py $g 4096 5000 250 chains 2>&1 | grep -v amdgpu.ids | tee $D/soak_${g}_chains.log | tail -2
+  SSD_AQL_ALTERNATE=1 SSD_AQL_ALWAYS_FORK=1 python3 tools/soak_parity.py $g 4096 3000 250 chains 2>&1 | grep -v amdgpu.ids | tee $D/soak_${g}_chains_alternate.log | tail -2
+  python3 tools/soak_parity.py $g 4096 3000 250 fused 2>&1 | grep -v amdgpu.ids | tee $D/soak_${g}_fused.log | tail -2
+done
