@@ -142,9 +142,9 @@ def time_rollout(torch, eng, ring, steps, warmup, step0=0, **kw):
     wchunk = max(4, warmup // 4)
     for w0 in range(0, warmup, wchunk):
         run(step0 + w0, min(wchunk, warmup - w0))
+    ev0.record()                                   # (before the opening synchronize: see main())
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev0.record()
     run(step0 + warmup, steps)
     ev1.record()
     enq = time.perf_counter() - t0
@@ -320,9 +320,13 @@ def main():
         run_steps(w0, min(wchunk, args.warmup - w0))
     torch.cuda.synchronize()
     parallel.barrier(dist, local_rank)
+    # The opening event is recorded BEFORE the opening synchronize: the timed region then starts on an idle stream, as a rollout
+    # call after any synchronize does (an event record just ahead of the call would make the library fork from a "busy" stream:
+    # ~20 us of a 20-step region).  The HIP-event interval therefore also covers that synchronize's return (~10 us): it is the
+    # secondary clock; `value`, `ms_per_step` and `roofline.frac` use the wall clock below.
+    ev0.record()                                   # torch's current stream == the stream the kernels are launched on
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev0.record()                                   # torch's current stream == the stream the kernels are launched on
     run_steps(args.warmup, args.steps)
     ev1.record()
     enq = time.perf_counter() - t0                 # host time to enqueue the K steps (must stay below the device time)
