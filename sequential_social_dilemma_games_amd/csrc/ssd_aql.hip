@@ -57,6 +57,8 @@ namespace {
     X(hsa_executable_freeze) X(hsa_executable_get_symbol_by_name) X(hsa_executable_symbol_get_info) X(hsa_status_string)           \
     X(hsa_signal_wait_scacquire)
 
+constexpr int kPoolQueues = 3;
+
 struct Api {
 #define X(f) decltype(&::f) f = nullptr;
     SSD_HSA_FUNCS(X)
@@ -72,6 +74,11 @@ struct DeviceCtx {
     hsa_executable_t exe{};
     std::unordered_map<const void *, Kernel> kernels;     // by host stub
     std::string why;                                      // why not ok
+    // the device's dispatch queues, shared by every handle on it (queues are scarce: see queue_create), and what they share
+    struct Queue *pool[kPoolQueues] = {};
+    std::mutex enqueue_mu;                                // one rollout call writes packets at a time
+    uint32_t *abort_host = nullptr;                       // host memory (device-mapped): a queue of the device reported an error
+    void *abort_dev = nullptr;
 };
 std::mutex g_mu;
 bool g_api_tried = false, g_api_ok = false;
@@ -244,8 +251,7 @@ struct Queue {
     uint64_t rung = 0;                  // packets below this index have been handed to the doorbell
     uint32_t mask = 0;
     std::atomic<int> error{0};
-    uint32_t *abort_flag = nullptr;             // host memory the waiting kernel looks at: set on a queue error
-    void *flag_kernarg = nullptr;               // (host kernarg pool) the flag kernel's one argument: the join counter
+    uint32_t *abort_flag = nullptr;             // host memory the waiting kernels look at: set on a queue error
     Kernel flag_kernel{};
     bool attach_signal = false;
     hsa_signal_t done_signal{};                 // completion signal of the join packet in synchronous mode (join_and_wait)
@@ -260,17 +266,22 @@ static void queue_error_cb(hsa_status_t status, hsa_queue_t *, void *data) {
     fprintf(stderr, "[ssd aql] queue error: %s\n", msg ? msg : "?");
 }
 
-Queue *queue_create(int device, unsigned long long *join_counter, uint32_t *abort_flag) {
-    DeviceCtx *c = device_ctx(device);
-    if (!c) return nullptr;
+static void queue_destroy(Queue *Q) {
+    if (!Q) return;
+    if (Q->q) g_api.hsa_queue_destroy(Q->q);
+    if (Q->done_signal.handle) g_api.hsa_signal_destroy(Q->done_signal);
+    delete Q;
+}
+
+static Queue *queue_create(DeviceCtx *c) {
     Queue *Q = new Queue();
     Q->ctx = c;
     static const uint32_t qsize = [] { const char *v = getenv("SSD_AQL_QUEUE_SIZE"); int n = v ? atoi(v) : 4096; return (uint32_t)(n >= 64 ? n : 4096); }();
     uint32_t size = 64;
     while (size < qsize) size <<= 1;
-    // (a handle's total matters: with 4 queues of its own beside the HIP runtime's -- even idle ones -- every launch of the
-    // process slowed to ~30 us on this device, the hardware scheduler then time-slices its queue slots; 3 were fine: the
-    // library never creates more than one per chain and rollouts use 2)
+    // (a process's total matters: with 4 queues of the library's beside the HIP runtime's -- even idle ones -- every launch of the
+    // process slowed to ~30 us on this device, the hardware scheduler then time-slices its queue slots; 3 were fine.  Hence ONE
+    // pool of at most kPoolQueues queues per device, shared by all handles; rollouts use 2, or 3 from 6144 envs)
     if (g_api.hsa_queue_create(c->gpu, size, HSA_QUEUE_TYPE_SINGLE, queue_error_cb, Q, UINT32_MAX, UINT32_MAX, &Q->q) != HSA_STATUS_SUCCESS) {
         say("hsa_queue_create failed");
         delete Q;
@@ -279,27 +290,49 @@ Queue *queue_create(int device, unsigned long long *join_counter, uint32_t *abor
     if (g_api.hsa_signal_create(0, 0, nullptr, &Q->done_signal) != HSA_STATUS_SUCCESS) Q->done_signal.handle = 0;
     Q->mask = Q->q->size - 1;
     Q->widx = Q->rung = g_api.hsa_queue_load_read_index_scacquire(Q->q);
-    Q->abort_flag = abort_flag;
-    bool ok = lookup(device, flag_kernel_fn(), &Q->flag_kernel);
-    if (ok) ok = g_api.hsa_amd_memory_pool_allocate(c->host_kernarg_pool, 64, 0, &Q->flag_kernarg) == HSA_STATUS_SUCCESS &&
-                 g_api.hsa_amd_agents_allow_access(1, &c->gpu, nullptr, Q->flag_kernarg) == HSA_STATUS_SUCCESS;
-    if (!ok) {
-        say("flag kernel setup failed");
+    Q->abort_flag = c->abort_host;
+    if (!lookup(c->device, flag_kernel_fn(), &Q->flag_kernel)) {
+        say("flag kernel not found");
         queue_destroy(Q);
         return nullptr;
     }
-    std::memset(Q->flag_kernarg, 0, 64);
-    std::memcpy(Q->flag_kernarg, &join_counter, sizeof(void *));
     return Q;
 }
 
-void queue_destroy(Queue *Q) {
-    if (!Q) return;
-    if (Q->q) g_api.hsa_queue_destroy(Q->q);
-    if (Q->done_signal.handle) g_api.hsa_signal_destroy(Q->done_signal);
-    if (Q->flag_kernarg) g_api.hsa_amd_memory_pool_free(Q->flag_kernarg);
-    delete Q;
+// Queue `index` (0 .. pool_size() - 1) of the device's pool, created on first use; nullptr if that fails.
+Queue *pool_queue(int device, int index) {
+    DeviceCtx *c = device_ctx(device);
+    if (!c || index < 0 || index >= kPoolQueues) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!c->abort_host) {
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        c->abort_host = static_cast<uint32_t *>(h); c->abort_dev = d;
+        *c->abort_host = 0;
+    }
+    // (lookup() takes g_mu itself: resolve the flag kernel before)
+    if (!c->pool[index]) {
+        g_mu.unlock();
+        Queue *Q = queue_create(c);
+        g_mu.lock();
+        if (!c->pool[index]) c->pool[index] = Q; else if (Q) queue_destroy(Q);
+    }
+    return c->pool[index];
 }
+int pool_size() { return kPoolQueues; }
+std::mutex &enqueue_mutex(int device) { return g_dev[device].enqueue_mu; }
+const uint32_t *abort_flag_dev(int device) { return static_cast<const uint32_t *>(g_dev[device].abort_dev); }
+
+// A small block of host kernarg memory the device can read (a handle's flag-kernel argument).
+void *host_kernarg_alloc(int device, size_t bytes) {
+    DeviceCtx *c = device_ctx(device);
+    void *p = nullptr;
+    if (!c || g_api.hsa_amd_memory_pool_allocate(c->host_kernarg_pool, bytes, 0, &p) != HSA_STATUS_SUCCESS) return nullptr;
+    if (g_api.hsa_amd_agents_allow_access(1, &c->gpu, nullptr, p) != HSA_STATUS_SUCCESS) { g_api.hsa_amd_memory_pool_free(p); return nullptr; }
+    std::memset(p, 0, bytes);
+    return p;
+}
+void host_kernarg_free(void *p) { if (p && g_api_ok) g_api.hsa_amd_memory_pool_free(p); }
 
 bool queue_failed(const Queue *Q) { return Q->error.load() != 0; }
 
@@ -357,20 +390,21 @@ void ring(Queue *Q) {
 uint64_t write_index(const Queue *Q) { return Q->widx; }
 uint64_t read_index(const Queue *Q) { return g_api.hsa_queue_load_read_index_scacquire(Q->q); }
 
-// JOIN: after everything enqueued so far on Q, bump the join counter; the packet's system-scope release makes the rollout's
-// results visible to everybody.  (The caller's stream waits for the counter with ssd_wait_counter_kernel.)
-void join(Queue *Q) {
-    dispatch(Q, Q->flag_kernel, 1, 64, 0, Q->flag_kernarg, /*barrier=*/true, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM);
+// JOIN: after everything enqueued so far on Q, bump a join counter (`flag_kernarg`: host kernarg block holding the counter's
+// device address); the packet's system-scope release makes the rollout's results visible to everybody.  (The caller's stream
+// waits for the counter with ssd_wait_counter_kernel.)
+void join(Queue *Q, const void *flag_kernarg) {
+    dispatch(Q, Q->flag_kernel, 1, 64, 0, flag_kernarg, /*barrier=*/true, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM);
     ring(Q);
 }
 
 // Synchronous join (SSD_AQL_SYNC=1: profiling with serialised kernels, where a kernel that waits for another queue's kernel
 // would wait forever): the join packet carries a completion signal and the HOST waits for it.
-bool join_and_wait(Queue *Q) {
+bool join_and_wait(Queue *Q, const void *flag_kernarg) {
     if (!Q->done_signal.handle) return false;
     g_api.hsa_signal_store_screlease(Q->done_signal, 1);
     Q->attach_signal = true;
-    join(Q);
+    join(Q, flag_kernarg);
     Q->attach_signal = false;
     while (g_api.hsa_signal_wait_scacquire(Q->done_signal, HSA_SIGNAL_CONDITION_LT, 1, 1000000, HSA_WAIT_STATE_BLOCKED) >= 1)
         if (Q->error.load()) return false;

@@ -2,6 +2,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <mutex>
+
 namespace ssd {
 namespace aql {
 
@@ -12,10 +14,12 @@ bool available(int device);                        // HSA runtime reachable, age
 const char *why_not(int device);
 bool lookup(int device, const void *host_fn, Kernel *out);   // kernel descriptor of the instantiation behind a HIP host stub
 
-// `join_counter`: device memory, 8 bytes, zeroed; every join() on the queue adds 1 to it once the queue's earlier packets are done.
-// `abort_flag`: host memory (device-mapped), set to 1 when the runtime reports an error on the queue.
-Queue *queue_create(int device, unsigned long long *join_counter, uint32_t *abort_flag);
-void queue_destroy(Queue *q);
+// The device's dispatch queues: a pool of at most pool_size() queues per device, shared by every handle on it (queues are
+// scarce: ssd_aql.hip), created on first use and kept for the life of the process.  One rollout call writes packets at a time
+// (enqueue_mutex).
+Queue *pool_queue(int device, int index);
+int pool_size();
+std::mutex &enqueue_mutex(int device);
 bool queue_failed(const Queue *q);                 // the runtime reported an error on the queue (the path is then abandoned)
 uint64_t write_index(const Queue *q);              // index the next packet will get
 uint64_t read_index(const Queue *q);               // packets below this index have been consumed by the command processor
@@ -25,8 +29,13 @@ void dispatch(Queue *q, const Kernel &k, uint32_t grid_x, uint32_t block_x, uint
               bool barrier, int acquire_scope, int release_scope);
 void barrier_and(Queue *q, uint64_t dep_signal_handle);      // the queue waits until the signal's value is 0
 void ring(Queue *q);                               // doorbell: hand everything written so far to the command processor
-bool join_and_wait(Queue *q);                      // synchronous form: the host waits until the join packet has completed
-void join(Queue *q);                               // after everything enqueued on q so far: join_counter += 1 (and a system-scope release)
+// after everything enqueued on q so far: the counter whose device address `flag_kernarg` (a host_kernarg_alloc block) holds += 1,
+// with a system-scope release; join_and_wait: the host waits until that packet has completed
+void join(Queue *q, const void *flag_kernarg);
+bool join_and_wait(Queue *q, const void *flag_kernarg);
+void *host_kernarg_alloc(int device, size_t bytes);   // zeroed host kernarg memory the device can read
+void host_kernarg_free(void *p);
+const uint32_t *abort_flag_dev(int device);        // device address of the word that is set when a queue of the device fails
 
 uint64_t signal_create(long long initial);         // 0 on failure
 void signal_destroy(uint64_t handle);

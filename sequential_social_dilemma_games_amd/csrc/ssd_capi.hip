@@ -64,7 +64,7 @@ struct AqlState {
     int fork_next = 0;
     unsigned long long *join_counter = nullptr;     // device memory: += 1 by every chain's last packet of a call
     unsigned long long joins = 0;                   // value it reaches when everything enqueued so far is done
-    uint32_t *abort_flag = nullptr;                 // host memory (device-mapped): a queue reported an error
+    void *flag_kernarg = nullptr;                   // host kernarg block: the flag kernel's argument (= join_counter)
     struct Key {
         const void *obs = nullptr, *rew = nullptr, *done = nullptr;
         int32_t ring = 0, f32 = 0, num_actions = 0, chains = 0, horizon = 0, coherent = 0, split = 0;
@@ -708,10 +708,10 @@ static void stop_workers(ssd_env *env) {
 static void aql_teardown(ssd_env *env) {
     if (!env->aql) return;
     AqlState &A = *env->aql;
-    for (int c = 0; c < 8; ++c) if (A.q[c]) ssd::aql::queue_destroy(A.q[c]);
+    // (the queues belong to the device's pool and stay; the handle's work in them is done: ssd_destroy synchronised the device)
     for (uint64_t h : A.fork_sig) ssd::aql::signal_destroy(h);
     if (A.join_counter) (void)hipFree(A.join_counter);
-    if (A.abort_flag) (void)hipHostFree(A.abort_flag);
+    ssd::aql::host_kernarg_free(A.flag_kernarg);
     for (auto &st : A.sets) if (st.dev) (void)hipFree(st.dev);
     for (int i = 0; i < 2; ++i) { if (A.snap_grid[i]) (void)hipFree(A.snap_grid[i]); if (A.snap_agents[i]) (void)hipFree(A.snap_agents[i]); }
     env->aql.reset();
@@ -732,22 +732,24 @@ static bool aql_ready(ssd_env *env, int chains) {
         void *ptr = nullptr;
         if (hipMalloc(&ptr, 8) != hipSuccess || hipMemset(ptr, 0, 8) != hipSuccess) { (void)hipGetLastError(); return false; }
         A.join_counter = static_cast<unsigned long long *>(ptr);
-        if (hipHostMalloc(&ptr, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
-        A.abort_flag = static_cast<uint32_t *>(ptr);
-        *A.abort_flag = 0;
+        A.flag_kernarg = ssd::aql::host_kernarg_alloc(env->device, 64);
+        if (!A.flag_kernarg) return false;
+        std::memcpy(A.flag_kernarg, &A.join_counter, sizeof(void *));
+        A.q[0] = ssd::aql::pool_queue(env->device, 0);
+        if (!A.q[0]) return false;
+        A.nq = 1;
         {   // first launches of the two helper kernels now (the runtime resolves a kernel on its first launch: ~50 us), not
             // inside somebody's first short rollout
-            void *abort_dev = nullptr;
-            (void)hipHostGetDevicePointer(&abort_dev, A.abort_flag, 0);
             ssd::aql::signal_set(A.fork_sig[0], 1);
             ssd::launch_signal_kernel(ssd::aql::signal_value_ptr(A.fork_sig[0]), nullptr);
-            ssd::launch_wait_counter_kernel(A.join_counter, 0, static_cast<const uint32_t *>(abort_dev), nullptr);
+            ssd::launch_wait_counter_kernel(A.join_counter, 0, ssd::aql::abort_flag_dev(env->device), nullptr);
             if (hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipGetLastError(); return false; }
         }
         A.ok = true;
     }
+    if (chains > ssd::aql::pool_size()) return false;              // (more chains than the device's pool has queues: HIP streams)
     while (A.nq < chains) {
-        A.q[A.nq] = ssd::aql::queue_create(env->device, A.join_counter, A.abort_flag);
+        A.q[A.nq] = ssd::aql::pool_queue(env->device, A.nq);
         if (!A.q[A.nq]) { A.ok = false; return false; }
         A.nq++;
     }
@@ -879,6 +881,8 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     AqlState::Set *st = aql_set(env, key, chains, jobs);
     if (!st) return 1;
     if (j0.n_steps == 0) return SSD_OK;
+    // (the queues are the device's, shared with the other handles on it: one call writes packets at a time)
+    std::lock_guard<std::mutex> enqueue_lock(ssd::aql::enqueue_mutex(env->device));
     // FORK: the chains wait (barrier-AND) for a signal that a one-wave kernel on the caller's stream zeroes -- unless the
     // stream has nothing pending, in which case there is nothing to wait for and the first step can start at once
     static const bool always_fork = [] { const char *v = getenv("SSD_AQL_ALWAYS_FORK"); return v && atoi(v) != 0; }();
@@ -942,19 +946,17 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     if (sync_mode) {
         bool ok = true;
         for (int c = 0; c < chains; ++c) ssd::aql::ring(A.q[c]);
-        for (int c = 0; c < chains; ++c) { ok = ssd::aql::join_and_wait(A.q[c]) && ok; st->last_use[c] = ssd::aql::write_index(A.q[c]); }
+        for (int c = 0; c < chains; ++c) { ok = ssd::aql::join_and_wait(A.q[c], A.flag_kernarg) && ok; st->last_use[c] = ssd::aql::write_index(A.q[c]); }
         A.joins += (unsigned long long)chains;
         if (!ok) { env->err = "the HSA runtime reported an error on a dispatch queue"; A.ok = false; return SSD_E_DEVICE; }
         return SSD_OK;
     }
     for (int c = 0; c < chains; ++c) {
-        ssd::aql::join(A.q[c]);
+        ssd::aql::join(A.q[c], A.flag_kernarg);
         st->last_use[c] = ssd::aql::write_index(A.q[c]);
     }
     A.joins += (unsigned long long)chains;
-    void *abort_dev = nullptr;
-    (void)hipHostGetDevicePointer(&abort_dev, A.abort_flag, 0);
-    ssd::launch_wait_counter_kernel(A.join_counter, A.joins, static_cast<const uint32_t *>(abort_dev), s);
+    ssd::launch_wait_counter_kernel(A.join_counter, A.joins, ssd::aql::abort_flag_dev(env->device), s);
     if (hipGetLastError() != hipSuccess) { env->err = "join kernel launch failed"; A.ok = false; return SSD_E_DEVICE; }
     for (int c = 0; c < chains; ++c) if (ssd::aql::queue_failed(A.q[c])) { env->err = "the HSA runtime reported an error on a dispatch queue"; A.ok = false; return SSD_E_DEVICE; }
     return SSD_OK;

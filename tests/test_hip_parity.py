@@ -697,3 +697,42 @@ def test_auto_reset_in_the_step_launch(cfg):
     for k in ("world", "pos", "orient", "episode", "t"):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     assert eng.status() == 0
+
+
+def test_handles_on_one_device_share_the_dispatch_queues():
+    """The library's dispatch queues belong to the device, not to a handle (a process gets slow with more than a few queues):
+    three live engines -- different games, sizes and chain counts -- take turns with rollout calls and per-step calls on the same
+    stream; each stays bit-exact against its oracle, and destroying one in the middle does not disturb the others."""
+    import torch
+    specs = [(K.GAME_HARVEST, K.HARVEST_MAP, 300, 5, 2), (K.GAME_CLEANUP, K.CLEANUP_MAP, 2100, 5, 3), (K.GAME_HARVEST, K.HARVEST_MAP, 64, 5, 1)]
+    engs, oras, bufs = [], [], []
+    for i, (game, amap, E, N, chains) in enumerate(specs):
+        eng = VecEngine(game, amap, num_envs=E, num_agents=N, seed=40 + i)
+        eng.set_rollout_chains(chains)
+        engs.append(eng)
+        oras.append(pyoracle.Oracle(game, amap, E, N, G.default_lut(), seed=40 + i))
+        bufs.append((torch.zeros((2, E, N, 15, 15, 3), dtype=torch.uint8, device="cuda"), torch.zeros((2, E, N), dtype=torch.int32, device="cuda")))
+    step0 = [0, 0, 0]
+    for rnd in range(4):
+        for i, eng in enumerate(engs):
+            if eng is None:
+                continue
+            n = 3 + 2 * rnd + i
+            eng.rollout_random(n, bufs[i][0], bufs[i][1], None, reset_every=7, step0=step0[i])
+            for k in range(step0[i], step0[i] + n):
+                if k % 7 == 0:
+                    oras[i].reset()
+                _, o_obs, o_rew, _ = oras[i].step_random()
+            step0[i] += n
+            last = (step0[i] - 1) % 2
+            np.testing.assert_array_equal(bufs[i][1][last].cpu().numpy(), o_rew, err_msg="engine %d round %d" % (i, rnd))
+            assert np.array_equal(bufs[i][0][last].cpu().numpy(), o_obs), "engine %d round %d: observations" % (i, rnd)
+        if rnd == 1:
+            engs[0].close()
+            engs[0] = None
+    for i, eng in enumerate(engs):
+        if eng is not None:
+            a, b = eng.get_state(), oras[i].get_state()
+            for key in ("world", "pos", "orient", "episode", "t"):
+                np.testing.assert_array_equal(a[key], b[key], err_msg="engine %d %s" % (i, key))
+            assert eng.status() == 0
