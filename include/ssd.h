@@ -135,8 +135,13 @@ int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, voi
  * only; the call enqueues on `stream` and returns.  Exactly the launches that n_steps calls of ssd_step_random (and
  * ssd_reset) would make -- the point is the host: one library call instead of one per step keeps a launch-bound
  * rollout fed.  Envs are independent, so the library may split the batch into up to 8 env ranges ("chains") that it
- * enqueues on streams of its own, forked from and joined back into `stream`: the launches of one chain then overlap
- * the dispatch / drain gaps of the others.  Results do not depend on the number of chains. */
+ * enqueues on queues of its own, forked from and joined back into `stream`: the launches of one chain then overlap
+ * the dispatch / drain gaps of the others.  Results do not depend on the number of chains.
+ * How the launches are issued is the library's business and does not change what the caller sees on `stream`: up to 3
+ * chains are written as AQL packets into HSA queues the library owns (one pool per device), with the observation rendering
+ * of a step carried out by extra workgroups of the next step's launch where that pays; otherwise, and
+ * with SSD_AQL=0 in the environment, through hipLaunchKernel on HIP streams.  Every step's outputs are in their ring slots
+ * when the work enqueued by the call has completed on `stream`. */
 int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32_t reset_every, int32_t step0,
                        void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream);
 

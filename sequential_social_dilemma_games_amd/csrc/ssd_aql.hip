@@ -1,25 +1,28 @@
 // csrc/ssd_aql.hip -- the library's own dispatch path: AQL packets written straight into HSA queues it owns.
 //
-// Why.  A rollout at the named batch (4096 envs) is launch-bound: the step kernel runs ~4.5 us, hipLaunchKernel costs
-// 2.3-3 us of host time per launch behind a runtime lock (two launches per step), and a short ssd_rollout_random call
-// (rollout.py:58-70 called per training iteration) paid ~50-100 us of runtime bookkeeping on top.  An AQL kernel-dispatch
-// packet is 64 bytes; writing one and ringing the doorbell takes ~0.1 us.  So ssd_rollout_random writes its step launches
-// itself:
-//   * one HSA user-mode queue per chain (env range), created once per handle;
-//   * the code object is the one hipcc built for the HIP path (the offload bundle of ssd_kernels.o, embedded a second time
-//     as plain data by ssd_codeobj.S), loaded through the HSA executable API; a kernel is looked up by the name HIP reports
-//     for the same __global__ stub (hipKernelNameRefByPtr), so both paths run the very same instantiation;
-//   * kernel arguments do not change from step to step (the state pointers, the output slot, the env range): they are
-//     written ONCE per (chain, ring slot, reset / step) into device memory and every packet of the rollout points at them --
-//     no per-launch argument traffic, and waves fetch their arguments from HBM, not from host memory;
+// Why.  A rollout at the named batch (4096 envs) is a chain of dependent ~4 us kernels: hipLaunchKernel costs 2.3-3 us of host
+// time per launch behind a runtime lock (two launches per step), a short ssd_rollout_random call (rollout.py:58-70 called per
+// training iteration) paid 50-250 us of runtime bookkeeping on top, and nothing about the packets could be chosen.  An AQL
+// kernel-dispatch packet is 64 bytes; writing one and ringing the doorbell takes ~0.15 us.  So ssd_rollout_random writes its step
+// launches itself (ssd_capi.hip: rollout_aql); this file is the mechanism:
+//   * the HSA runtime is the one the process already runs on (the HIP runtime's dependency, found with RTLD_NOLOAD);
+//   * queues: a pool of at most kPoolQueues HSA user-mode queues per DEVICE, shared by all handles (queues are scarce, see
+//     queue_create), one per chain of a rollout;
+//   * the code object is the one hipcc built for the HIP path (the offload bundle of ssd_kernels.o, embedded a second time as
+//     plain data by ssd_codeobj.S), loaded through the HSA executable API; a kernel is looked up by the name HIP reports for the
+//     same __global__ stub (hipKernelNameRefByPtr), so both paths run the very same instantiation;
+//   * kernel arguments are the caller's business (ssd_capi.hip keeps them static, in device memory): dispatch() takes a pointer;
 //   * ordering against the caller's HIP stream: FORK -- a one-wave HIP kernel on the stream zeroes an HSA signal that a
-//     barrier-AND packet at the head of every chain waits on; JOIN -- each chain ends with a one-wave dispatch (barrier bit)
-//     that bumps a counter in HIP signal memory, and the stream waits for it with hipStreamWaitValue64.
-// Packets within a chain carry the barrier bit and agent-scope acquire / release fences: the same ordering and visibility a
-// HIP stream gives consecutive kernels.
+//     barrier-AND packet at the head of every chain waits on; JOIN -- each chain ends with a one-wave dispatch (barrier bit,
+//     system-scope release) that bumps a counter in device memory, which a one-wave kernel on the stream sleeps on
+//     (hipStreamWaitValue64 instead made the command processor poll host memory for the stream's queue, and that slowed the
+//     dispatch queues sharing its micro-engine: 6.7 against 6.06 us per step); join_and_wait() is the synchronous form for tools
+//     that serialise kernels.
+// Packets within a chain carry the barrier bit; their fence scopes are the caller's choice (agent / agent = what the HIP runtime
+// writes for its own kernel packets; none for the coherent kernel variants).
 //
-// Nothing here computes anything: if the HSA runtime, the queue or the code object cannot be set up, aql::available()
-// is false and ssd_rollout_random issues the same launches through hipLaunchKernel.  SSD_AQL=0 forces that.
+// Nothing here computes anything: if the HSA runtime, a queue or the code object cannot be set up, aql::available() is false
+// and ssd_rollout_random issues the same launches through hipLaunchKernel.  SSD_AQL=0 forces that.
 #include <hip/hip_runtime.h>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
