@@ -335,6 +335,7 @@ def main():
     parallel.barrier(dist, local_rank)             # (the closing barrier: everybody is done before anybody reports; its own
     torch.cuda.synchronize()                       #  latency, ~1 ms of RCCL, is not part of any rank's K steps)
     dev_ms = ev0.elapsed_time(ev1)
+    path = eng.rollout_path() if use_rollout else None  # how the library dispatched the timed call (a fallback must not go unnoticed)
     if eng.status() != 0:
         raise SystemExit("device status word is non-zero")
     plain = use_rollout and not do_gather and not args.no_extras
@@ -376,7 +377,11 @@ def main():
                                    % (args.game, eng.H, eng.W, n_agents, E, HORIZON),
                        "envs_per_gpu": E, "agents": n_agents, "obs": ("float32" if args.obs_f32 else "uint8") + " [E,N,15,15,3]", "launches_per_step": chains, "enqueue": ("ssd_rollout_random, %d chain(s) of %d envs" % (chains, E // chains)) if use_rollout else "one call per step",
                        "gather": ("one RCCL all-gather of obs and one of rewards per %d steps, overlapped with the next %d steps" % (GR, GR)) if do_gather else False, "parallelism": "env-shard x%d" % world,
-                       "rccl_ranks": dist.get_world_size() if dist is not None else 1},
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+                       "dispatch": ("%s, %d chain(s)%s%s%s" % ("AQL packets in the library's own HSA queues" if path["aql"] else "hipLaunchKernel on HIP streams",
+                                                                path["chains"], ", coherent kernel variant (no fence between a chain's launches)" if path["coherent"] else "",
+                                                                ", observations rendered by the next step's launch" if path["split"] else "",
+                                                                ", pipelined launches" if path["pipelined"] else "")) if path else "one call per step (hipLaunchKernel)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "ssd::ssd_env_kernel<%d, 0, %s, ...>" % (game, "true" if args.obs_f32 else "false"), "bytes_per_env_step": bytes_env,

@@ -145,6 +145,16 @@ int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, voi
 int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32_t reset_every, int32_t step0,
                        void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream);
 
+/* How the last ssd_rollout_random call of the handle was dispatched (a bit mask; 0 before the first call):
+ *   SSD_PATH_AQL       the launches were written as AQL packets into the library's own queues (else: hipLaunchKernel)
+ *   SSD_PATH_COHERENT  ... with the kernel variant that needs no cache write-back between a chain's launches
+ *   SSD_PATH_SPLIT     ... and every step's observations rendered by extra workgroups of the next step's launch
+ *   SSD_PATH_FUSED / SSD_PATH_PIPELINED   the call ran as the fused rollout kernel / with pipelined launches
+ *   bits 8..11         number of chains
+ * So that a caller (a test, a benchmark) can tell a silent fallback from the path it meant to measure. */
+enum { SSD_PATH_AQL = 1, SSD_PATH_COHERENT = 2, SSD_PATH_SPLIT = 4, SSD_PATH_FUSED = 8, SSD_PATH_PIPELINED = 16 };
+int ssd_rollout_path(const ssd_env *env);
+
 /* Number of chains ssd_rollout_random uses: 1..8, or 0 = automatic (1 below 2048 envs, 3 from 6144 to 24576, else 2). */
 int ssd_set_rollout_chains(ssd_env *env, int32_t chains);
 

@@ -12,11 +12,12 @@ LIB_PATH = os.environ.get("SSD_LIB_PATH") or os.path.join(_PKG, "libssd_hip.so")
 
 SSD_OK, SSD_E_INVALID, SSD_E_DEVICE, SSD_E_NOMEM, SSD_E_STATE = 0, -1, -2, -3, -4
 SSD_HOST_PTRS, SSD_NO_ROTATE, SSD_OBS_F32, SSD_ROLLOUT_FUSED, SSD_AUTO_RESET, SSD_ROLLOUT_PIPELINED = 1, 2, 4, 8, 16, 32
+SSD_PATH_AQL, SSD_PATH_COHERENT, SSD_PATH_SPLIT, SSD_PATH_FUSED, SSD_PATH_PIPELINED = 1, 2, 4, 8, 16
 SSD_ST_BAD_ACTION, SSD_ST_NO_SPAWN, SSD_ST_MOVE_LOOKUP, SSD_ST_PIPE_TIMEOUT = 1, 2, 4, 8
 ABI_VERSION = 1
 
 # every symbol include/ssd.h declares
-SYMBOLS = ("ssd_create", "ssd_destroy", "ssd_reset", "ssd_step", "ssd_step_random", "ssd_rollout_random", "ssd_set_rollout_chains", "ssd_observe",
+SYMBOLS = ("ssd_create", "ssd_destroy", "ssd_reset", "ssd_step", "ssd_step_random", "ssd_rollout_random", "ssd_rollout_path", "ssd_set_rollout_chains", "ssd_observe",
            "ssd_get_state", "ssd_set_state", "ssd_get_waste_count", "ssd_render_full", "ssd_render_frames", "ssd_agent_action_obs", "ssd_set_horizon", "ssd_potential_waste_area",
            "ssd_device_status", "ssd_synchronize", "ssd_last_error", "ssd_abi_version")
 
@@ -79,6 +80,7 @@ def lib():
         L.ssd_step.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp]
         L.ssd_step_random.argtypes = [vp, i32, vp, vp, vp, vp, u32, vp]
         L.ssd_rollout_random.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, i32, u32, vp]
+        L.ssd_rollout_path.argtypes = [vp]
         L.ssd_set_rollout_chains.argtypes = [vp, i32]
         L.ssd_observe.argtypes = [vp, vp, u32, vp]
         L.ssd_get_state.argtypes = [vp] + [vp] * 6

@@ -135,6 +135,7 @@ struct ssd_env {
     // mixes the two styles -- tensors on a non-blocking side stream, then a *_host call -- gets program order.
     hipStream_t last_stream = nullptr;
     bool last_stream_set = false;
+    int last_path = 0;                                   // SSD_PATH_* of the last ssd_rollout_random call
     std::string err;
 };
 
@@ -877,6 +878,7 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     static const int env_split = [] { const char *v = getenv("SSD_AQL_SPLIT"); return v ? atoi(v) : 1; }();
     key.split = (coherent && env_split != 0 && j0.obs != nullptr && per_launch <= 2304) ? 1 : 0;   // (the argument set holds both forms' launches)
     const bool split = key.split && j0.n_steps >= 4;
+    env->last_path |= SSD_PATH_AQL | (coherent ? SSD_PATH_COHERENT : 0) | (split ? SSD_PATH_SPLIT : 0);
     if ((size_t)chains * j0.ring > 2048) return 1;                     // (argument blocks: 10 x 512 B per chain and slot)
     AqlState::Set *st = aql_set(env, key, chains, jobs);
     if (!st) return 1;
@@ -1033,6 +1035,7 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
     if (chains > 8) chains = 8;
     if (chains > env->E) chains = env->E;
     if (chains < 1) chains = 1;
+    env->last_path = (chains << 8) | ((flags & SSD_ROLLOUT_FUSED) ? SSD_PATH_FUSED : 0) | (pipelined ? SSD_PATH_PIPELINED : 0);
     for (int c = 1; pipelined && c < chains; ++c) { int rc = ensure_chain_pipe(env, c); if (rc) return rc; }
     auto range = [&](int c) { return (int)(((long long)env->E * c) / chains); };
     auto job_of = [&](int c, hipStream_t cs) {
@@ -1316,6 +1319,8 @@ int ssd_set_horizon(ssd_env *env, int32_t horizon) {
     env->p.horizon = horizon;
     return SSD_OK;
 }
+
+int ssd_rollout_path(const ssd_env *env) { return env ? env->last_path : SSD_E_INVALID; }
 
 int ssd_set_rollout_chains(ssd_env *env, int32_t chains) {
     if (!env || chains < 0 || chains > 8) return SSD_E_INVALID;

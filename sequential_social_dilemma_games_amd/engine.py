@@ -210,6 +210,13 @@ class VecEngine(object):
         else:
             self._count_steps(n_steps)
 
+    def rollout_path(self):
+        """How the last rollout_random() call was dispatched: {"aql", "coherent", "split", "fused", "pipelined": bool, "chains": n}
+        (ssd_rollout_path) -- lets a benchmark or a test tell a silent fallback from the path it meant to measure."""
+        m = self._L.ssd_rollout_path(self._h)
+        return {"aql": bool(m & _capi.SSD_PATH_AQL), "coherent": bool(m & _capi.SSD_PATH_COHERENT), "split": bool(m & _capi.SSD_PATH_SPLIT),
+                "fused": bool(m & _capi.SSD_PATH_FUSED), "pipelined": bool(m & _capi.SSD_PATH_PIPELINED), "chains": (m >> 8) & 15}
+
     def observe(self, rotate=True, obs=None):
         torch, dev = self._torch()
         if obs is None:

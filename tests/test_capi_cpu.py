@@ -60,7 +60,7 @@ def test_python_constants_match_the_header():
     text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ssd.h")).read()
 
     def value(name):
-        m = re.search(r"\b%s\s*=\s*([^,/\n]+)" % name, text)
+        m = re.search(r"\b%s\s*=\s*([^,/\n}]+)" % name, text)
         assert m, name
         expr = m.group(1).strip().replace("u", "")
         return int(eval(expr))                                   # "1 << 3", "-2", ...
@@ -68,6 +68,8 @@ def test_python_constants_match_the_header():
     for name in ("SSD_HOST_PTRS", "SSD_NO_ROTATE", "SSD_OBS_F32", "SSD_ROLLOUT_FUSED", "SSD_AUTO_RESET", "SSD_ROLLOUT_PIPELINED"):
         assert getattr(_capi, name) == value(name), name
     for name in ("SSD_ST_BAD_ACTION", "SSD_ST_NO_SPAWN", "SSD_ST_MOVE_LOOKUP", "SSD_ST_PIPE_TIMEOUT"):
+        assert getattr(_capi, name) == value(name), name
+    for name in ("SSD_PATH_AQL", "SSD_PATH_COHERENT", "SSD_PATH_SPLIT", "SSD_PATH_FUSED", "SSD_PATH_PIPELINED"):
         assert getattr(_capi, name) == value(name), name
     assert value("SSD_OK") == 0 and value("SSD_E_DEVICE") == -2
     assert int(re.search(r"#define SSD_ABI_VERSION (\d+)", text).group(1)) == _capi.lib().ssd_abi_version()

@@ -231,6 +231,31 @@ def test_the_exact_bench_path_at_full_size(game):
     _rollout_vs_oracle(game, amap, 4096, 5, seed=0, steps=45, step0=975, every=1000, ring=1, chains=2)
 
 
+def test_the_bench_configuration_takes_the_native_dispatch_path():
+    """What bench.py reports must be what it meant to measure: at the headline configuration a rollout call goes through the
+    library's own dispatch queues with the coherent kernel variant and split rendering (ssd_rollout_path) -- unless the
+    environment says otherwise.  A silent fallback to hipLaunchKernel would still pass every parity test."""
+    import torch
+    eng = VecEngine(K.GAME_HARVEST, None, num_envs=4096, num_agents=5, seed=0)
+    out = eng.alloc_outputs()
+    ring = tuple(t.unsqueeze(0) for t in out)
+    eng.set_rollout_chains(2)
+    assert eng.rollout_path() == {"aql": False, "coherent": False, "split": False, "fused": False, "pipelined": False, "chains": 0}
+    eng.rollout_random(20, *ring, reset_every=1000)
+    torch.cuda.synchronize()
+    path = eng.rollout_path()
+    want_aql = os.environ.get("SSD_AQL", "1") != "0"
+    want_coh = want_aql and os.environ.get("SSD_AQL_COHERENT", "1") != "0"
+    want_split = want_coh and os.environ.get("SSD_AQL_SPLIT", "1") != "0"
+    assert path == {"aql": want_aql, "coherent": want_coh, "split": want_split, "fused": False, "pipelined": False, "chains": 2}, path
+    eng.rollout_random(3, *ring, reset_every=1000, step0=20)              # (short calls are not split)
+    assert eng.rollout_path()["split"] is False and eng.rollout_path()["aql"] == want_aql
+    eng.rollout_random(8, *ring, reset_every=1000, step0=23, fused=True)
+    assert eng.rollout_path()["fused"] and not eng.rollout_path()["aql"]
+    torch.cuda.synchronize()
+    assert eng.status() == 0
+
+
 @pytest.mark.parametrize("mode", ["calls", "chains", "chains3", "fused", "pipelined"])
 @pytest.mark.parametrize("cfg", ["harvest25x38", "cleanup48x36"])
 def test_enlarged_maps_at_their_bench_sizes(cfg, mode):
