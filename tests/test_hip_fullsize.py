@@ -219,6 +219,21 @@ def _rollout_vs_oracle(game, amap, E, N, seed, steps, step0, every, ring, chains
     a, b = eng.get_state(), ora.get_state()
     for key in ("world", "pos", "orient", "episode", "t"):
         np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    # ... and per-step launches (hipLaunchKernel, the plain kernels) continue from what the rollout left -- whatever dispatch
+    # path, kernel variant and workgroup mapping its launches used: a cache must not serve them an older copy of the state
+    out = eng.alloc_outputs()
+    for s in range(3):
+        o, r, _ = eng.step_random(out=out)
+        _, o_obs, o_rew, _ = ora.step_random()
+        np.testing.assert_array_equal(r.cpu().numpy(), o_rew, err_msg="rewards of per-step launch %d after the rollout" % s)
+        assert np.array_equal(o.cpu().numpy(), o_obs), "observations of per-step launch %d after the rollout differ" % s
+    # ... and another rollout after those
+    eng.rollout_random(ring + 4, obs, rew, done, reset_every=0, step0=step0 + steps)
+    for k in range(step0 + steps, step0 + steps + ring + 4):
+        _, o_obs, o_rew, _ = ora.step_random()
+    k = step0 + steps + ring + 3
+    np.testing.assert_array_equal(rew.cpu().numpy()[k % ring], o_rew, err_msg="rewards of the second rollout")
+    assert np.array_equal(obs.cpu().numpy()[k % ring], o_obs), "observations of the second rollout differ"
     assert eng.status() == 0
     eng.close()
 
