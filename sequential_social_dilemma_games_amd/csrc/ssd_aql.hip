@@ -306,20 +306,20 @@ static Queue *queue_create(DeviceCtx *c) {
 Queue *pool_queue(int device, int index) {
     DeviceCtx *c = device_ctx(device);
     if (!c || index < 0 || index >= kPoolQueues) return nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!c->abort_host) {
+            void *h = nullptr, *d = nullptr;
+            if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            c->abort_host = static_cast<uint32_t *>(h); c->abort_dev = d;
+            *c->abort_host = 0;
+        }
+        if (c->pool[index]) return c->pool[index];
+    }
+    Queue *Q = queue_create(c);                     // (takes g_mu itself, in lookup())
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!c->abort_host) {
-        void *h = nullptr, *d = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        c->abort_host = static_cast<uint32_t *>(h); c->abort_dev = d;
-        *c->abort_host = 0;
-    }
-    // (lookup() takes g_mu itself: resolve the flag kernel before)
-    if (!c->pool[index]) {
-        g_mu.unlock();
-        Queue *Q = queue_create(c);
-        g_mu.lock();
-        if (!c->pool[index]) c->pool[index] = Q; else if (Q) queue_destroy(Q);
-    }
+    if (!c->pool[index]) c->pool[index] = Q;
+    else if (Q) queue_destroy(Q);                   // (another thread was faster)
     return c->pool[index];
 }
 int pool_size() { return kPoolQueues; }
