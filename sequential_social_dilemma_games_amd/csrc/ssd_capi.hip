@@ -20,9 +20,7 @@
 
 #include "../../include/ssd.h"
 #include "ssd_internal.hpp"
-#ifndef SSD_STAMPS
 #include "ssd_aql.hpp"
-#endif
 
 using ssd::Params;
 
@@ -53,7 +51,6 @@ struct ChainWorker {
 // ssd_rollout_random's own dispatch path (ssd_aql.hip): one HSA queue per chain; per (chain, ring slot) the kernel arguments of
 // the step launch and of the reset launch, written once into device memory and reused by every packet ("sets", keyed by what
 // the caller passed); a small ring of HSA signals for the fork from the caller's stream.
-#ifndef SSD_STAMPS
 struct AqlState {
     bool tried = false, ok = false;
     ssd::aql::Queue *q[8] = {};
@@ -68,8 +65,9 @@ struct AqlState {
     struct Key {
         const void *obs = nullptr, *rew = nullptr, *done = nullptr;
         int32_t ring = 0, f32 = 0, num_actions = 0, chains = 0, horizon = 0, coherent = 0, split = 0;
+        const void *stamps = nullptr; uint32_t dbg_skip = 0;     // (diagnostic builds: part of the kernel arguments too)
         bool operator==(const Key &o) const {
-            return obs == o.obs && rew == o.rew && done == o.done && ring == o.ring && f32 == o.f32 && num_actions == o.num_actions &&
+            return stamps == o.stamps && dbg_skip == o.dbg_skip && obs == o.obs && rew == o.rew && done == o.done && ring == o.ring && f32 == o.f32 && num_actions == o.num_actions &&
                    chains == o.chains && horizon == o.horizon && coherent == o.coherent && split == o.split;
         }
     };
@@ -96,9 +94,6 @@ struct AqlState {
     Set sets[kSets];
     uint64_t clock = 0;
 };
-#else
-struct AqlState {};
-#endif
 
 struct ssd_env {
     int game = 0, H = 0, W = 0, WP = 0, S = 0, E = 0, N = 0, view_len = 7, V = 15, beam_len = 5;
@@ -705,7 +700,6 @@ static void stop_workers(ssd_env *env) {
     env->workers.clear();
 }
 
-#ifndef SSD_STAMPS
 static void aql_teardown(ssd_env *env) {
     if (!env->aql) return;
     AqlState &A = *env->aql;
@@ -854,6 +848,7 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     AqlState::Key key;
     key.obs = j0.obs; key.rew = j0.rew; key.done = j0.done; key.ring = j0.ring; key.f32 = (j0.flags & SSD_OBS_F32) ? 1 : 0;
     key.num_actions = j0.num_actions; key.chains = chains; key.horizon = env->p.horizon;
+    key.stamps = env->p.stamps; key.dbg_skip = env->p.dbg_skip;
     // Coherent chains: with a map-specific uint8 kernel (and its write-through observation stores: up to 16 384 envs per launch)
     // state and outputs move with agent-scope accesses only, so the step packets need no release fence (ssd_kernels.hip, PIPE = 2).
     // SSD_AQL_COHERENT=0 keeps the plain kernels with agent-scope acquire + release on every packet; SSD_AQL_ALTERNATE=1 (test)
@@ -963,9 +958,6 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     for (int c = 0; c < chains; ++c) if (ssd::aql::queue_failed(A.q[c])) { env->err = "the HSA runtime reported an error on a dispatch queue"; A.ok = false; return SSD_E_DEVICE; }
     return SSD_OK;
 }
-#else
-static void aql_teardown(ssd_env *) {}
-#endif
 
 int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32_t reset_every, int32_t step0,
                        void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream) {
@@ -1045,7 +1037,6 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
         j.obs = o; j.rew = rew; j.done = done; j.flags = flags; j.s = cs;
         return j;
     };
-#ifndef SSD_STAMPS
     if (!pipelined && !(flags & SSD_ROLLOUT_FUSED)) {
         // the library's own dispatch path: the same launches as below, written as AQL packets into its own queues
         ChainJob jobs[8];
@@ -1053,7 +1044,6 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
         const int rc = rollout_aql(env, chains, jobs, s);
         if (rc <= 0) return rc;
     }
-#endif
     if (chains <= 1) {
         int rc = rollout_chain(env, job_of(0, s));
         if (rc) env->err = "kernel launch failed in ssd_rollout_random";

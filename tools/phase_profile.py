@@ -30,7 +30,7 @@ def main():
     eng.reset(obs=out[0])
     for _ in range(200):
         eng.step_random(out=out)
-    stamps = torch.zeros((E, 16), dtype=torch.int64, device="cuda")
+    stamps = torch.zeros((2 * E, 16), dtype=torch.int64, device="cuda")   # [E:] the renderer waves of split rollouts
     L = _capi.lib()
     L.ssd_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
     L.ssd_debug_set_stamps(eng._h, C.c_void_p(stamps.data_ptr()))
@@ -51,7 +51,8 @@ def main():
             for _ in range(burst):
                 eng.step_random(out=out)
         torch.cuda.synchronize()
-        s = stamps.cpu().double()
+        s_all = stamps.cpu().double()
+        s, sb = s_all[:E], s_all[E:]
         d = s[:, 1:10] - s[:, 0:9]
         acc += d.mean(dim=0)
         t0 = s[:, 10].min()                        # s_memrealtime: 100 MHz, common to all XCDs
@@ -93,6 +94,22 @@ def main():
             print("      env %5d: %.2f us (start %.2f) slow-move %d shooters %d beams-code %d | " % (
                 w, float(dur[w]), float(starts[w]), int(s[w, 12]), int(s[w, 13]), int(s[w, 15]))
                 + " ".join("%s %d" % (n.split()[0], v) for n, v in zip(NAMES, d_last[w].tolist()) if n != "wg barrier"))
+    if chains and float(sb[:, 10].max()) > 0:
+        # split rollouts: the last launch's env waves (step k) and the renderer waves beside them / behind them.  The stamps of a
+        # renderer wave are those of the LAST launch it ran in: the renderer-only launch that ends the call (after the last step).
+        print("    dispatch path of the call: %s" % (eng.rollout_path(),))
+        for c in range(chains):
+            lo, hi = E * c // chains, E * (c + 1) // chains
+            a0, a1 = s[lo:hi, 10], s[lo:hi, 11]
+            b0, b1 = sb[lo:hi, 10], sb[lo:hi, 11]
+            base = float(a0.min())
+            us = lambda x: (float(x) - base) * 0.01
+            print("    chain %d: last step's env waves start %.2f..%.2f end %.2f..%.2f us | renderer-only launch after it: waves start %.2f..%.2f end %.2f..%.2f us"
+                  % (c, us(a0.min()), us(a0.max()), us(a1.min()), us(a1.max()), us(b0.min()), us(b0.max()), us(b1.min()), us(b1.max())))
+        bd = sb[:, 1:4] - sb[:, 0:3]
+        print("    renderer wave phases (cycles, mean): load snapshot %.0f, render + issue stores %.0f, stores landed %.0f; wave duration (us) median %.2f max %.2f"
+              % (float(bd[:, 0].mean()), float(bd[:, 1].mean()), float(bd[:, 2].mean()), float(((sb[:, 11] - sb[:, 10]) * 0.01).median()),
+                 float(((sb[:, 11] - sb[:, 10]) * 0.01).max())))
     if chains:
         for c in range(chains):
             lo, hi = E * c // chains, E * (c + 1) // chains
