@@ -185,21 +185,28 @@ class VecEngine(object):
         its steps; same results, uint8 observations only.
         pipelined=True: ask for SSD_ROLLOUT_PIPELINED (step k+1 starts env by env while step k's slower envs are still at
         work; needs a ring of at least 2 slots and pays up to 2048 envs -- see include/ssd.h)."""
-        torch, dev = self._torch()
-        ring = int(obs.shape[0])
-        if obs.dtype not in (torch.uint8, torch.float32):
-            raise ValueError("obs must be uint8 or float32")
-        self._check_tensor(obs, (ring, self.E, self.N, self.V, self.V, 3), obs.dtype, "obs")
-        if rew is not None:
-            self._check_tensor(rew, (ring, self.E, self.N), torch.int32, "rew")
-        if done is not None:
-            self._check_tensor(done, (ring, self.E, self.N), torch.uint8, "done")
+        # (the buffers of the last call again: their checks and pointers are known -- a short call is mostly fixed costs)
+        cache = getattr(self, "_roll_cache", None)
+        if cache is not None and cache[0] is obs and cache[1] is rew and cache[2] is done:
+            po, pr, pd, ring, f32 = cache[3]
+        else:
+            torch, dev = self._torch()
+            ring = int(obs.shape[0])
+            if obs.dtype not in (torch.uint8, torch.float32):
+                raise ValueError("obs must be uint8 or float32")
+            self._check_tensor(obs, (ring, self.E, self.N, self.V, self.V, 3), obs.dtype, "obs")
+            if rew is not None:
+                self._check_tensor(rew, (ring, self.E, self.N), torch.int32, "rew")
+            if done is not None:
+                self._check_tensor(done, (ring, self.E, self.N), torch.uint8, "done")
+            po, pr, pd, f32 = self._dp(obs), self._dp(rew), self._dp(done), (_capi.SSD_OBS_F32 if obs.dtype == torch.float32 else 0)
+            self._roll_cache = (obs, rew, done, (po, pr, pd, ring, f32))
         na = self.num_actions if num_actions is None else int(num_actions)
-        _capi.check(self._L.ssd_rollout_random(self._h, na, int(n_steps), int(reset_every), int(step0), self._dp(obs), self._dp(rew),
-                                               self._dp(done), ring, (_capi.SSD_OBS_F32 if obs.dtype == torch.float32 else 0) |
-                                               (_capi.SSD_ROLLOUT_FUSED if fused else 0) |
-                                               (_capi.SSD_ROLLOUT_PIPELINED if pipelined else 0),
-                                               self._stream()), self._h)
+        rc = self._L.ssd_rollout_random(self._h, na, int(n_steps), int(reset_every), int(step0), po, pr, pd, ring,
+                                        f32 | (_capi.SSD_ROLLOUT_FUSED if fused else 0) | (_capi.SSD_ROLLOUT_PIPELINED if pipelined else 0),
+                                        self._stream())
+        if rc:
+            _capi.check(rc, self._h)
         n_steps, reset_every, step0 = int(n_steps), int(reset_every), int(step0)
         last = None                                  # index of the last step of this call that a full reset preceded
         if reset_every > 0 and n_steps > 0:
