@@ -87,6 +87,31 @@ def test_pipelined_handover_between_xcds():
     assert r.returncode == 0 and "soak ok" in out, out[-2000:]
 
 
+@pytest.mark.parametrize("knobs", [dict(SSD_AQL_ALTERNATE="1", SSD_AQL_ALWAYS_FORK="1"),
+                                   dict(SSD_AQL_ALTERNATE="1", SSD_AQL_SPLIT="0"),
+                                   dict(SSD_AQL_COHERENT="0"), dict(SSD_AQL="0")])
+@pytest.mark.parametrize("game", ["harvest", "cleanup"])
+def test_rollout_dispatch_modes_when_envs_change_xcd(game, knobs):
+    """The coherent chains of ssd_rollout_random carry no cache write-back or invalidate between launches: an env's state --
+    and, in split rollouts, the snapshot its observations are rendered from -- must reach the next launch through memory
+    wherever that launch's wave runs.  SSD_AQL_ALTERNATE halves the envs per workgroup on odd steps, so that most envs change
+    workgroup, and with it XCD and L2, from every launch to the next (and the renderer workgroups of a launch read what the
+    OTHER mapping wrote); SSD_AQL_ALWAYS_FORK makes every call fork from its stream.  4096 envs x 600 steps as rollout chains,
+    checked against the oracle every 100 steps.  Also: the same without split rendering, the plain kernels behind agent-scope
+    fences, and the hipLaunchKernel path (a process of its own each: the knobs are read once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("SSD_AQL", "SSD_AQL_ALTERNATE", "SSD_AQL_ALWAYS_FORK", "SSD_AQL_SPLIT", "SSD_AQL_COHERENT"):
+        env.pop(k, None)
+    env.update(knobs)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_parity.py"), game, "4096", "600", "100", "chains"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "soak ok" in out, out[-2000:]
+
+
 def test_pipelined_wait_is_bounded():
     """A wave of a pipelined launch that waits in vain gives up after a bounded number of polls, sets SSD_ST_PIPE_TIMEOUT and
     lets its launch finish.  SSD_PIPE_TEST_STALL makes the first launch of a call wait for a pass that never ran (a process
