@@ -458,7 +458,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             if (mode == kModeObserve && keep_beams) b0 = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + lane * 16);
         }
         // glyph -> RGB table of the observation phase, one copy per wave
-        const uint32_t lut_a = a_lut[lane], lut_b = a_lut[lane + 64];
+        // (a launch that renders nothing -- the env waves of a split rollout, a reset inside one -- needs no colour table)
+        uint32_t lut_a = 0, lut_b = 0;
+        if (a_obs) { lut_a = a_lut[lane]; lut_b = a_lut[lane + 64]; }
         const bool obs_f32 = F32 && a_obs;
         float4 flut = make_float4(0.f, 0.f, 0.f, 0.f), flut_b = flut;       // glyph -> (r, g, b, -) as float32, entries lane and lane + 64
         if (obs_f32) { flut = reinterpret_cast<const float4 *>(p.f32lut)[lane]; flut_b = reinterpret_cast<const float4 *>(p.f32lut)[lane + 64]; }
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             w0 = make_uint4(w0c.x, w0c.y, w0c.z, w0c.w);
         }
         uint32_t key = rfl(hdr.x), t = rfl(hdr.y), episode = rfl(hdr.z);
-        s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b;
+        if (a_obs) { s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b; }
         if (obs_f32) { reinterpret_cast<float4 *>(s_f32)[lane] = flut; reinterpret_cast<float4 *>(s_f32)[lane + 64] = flut_b; }
         uint32_t status = pipe_timeout ? kStPipeTimeout : 0u;
         uint32_t cell = areg & 0xFFFFu, orient = mode == kModeReset ? 2u : (areg >> 16) & 3u;   // lane = agent index
