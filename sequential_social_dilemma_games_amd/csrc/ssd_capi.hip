@@ -66,8 +66,9 @@ struct AqlState {
         const void *obs = nullptr, *rew = nullptr, *done = nullptr;
         int32_t ring = 0, f32 = 0, num_actions = 0, chains = 0, horizon = 0, coherent = 0, split = 0;
         const void *stamps = nullptr; uint32_t dbg_skip = 0;     // (diagnostic builds: part of the kernel arguments too)
+        const void *world = nullptr;                             // sets that are not split: the state buffer their blocks name
         bool operator==(const Key &o) const {
-            return stamps == o.stamps && dbg_skip == o.dbg_skip && obs == o.obs && rew == o.rew && done == o.done && ring == o.ring && f32 == o.f32 && num_actions == o.num_actions &&
+            return stamps == o.stamps && dbg_skip == o.dbg_skip && world == o.world && obs == o.obs && rew == o.rew && done == o.done && ring == o.ring && f32 == o.f32 && num_actions == o.num_actions &&
                    chains == o.chains && horizon == o.horizon && coherent == o.coherent && split == o.split;
         }
     };
@@ -77,18 +78,21 @@ struct AqlState {
         Key key;
         uint8_t *dev = nullptr;                     // [chains][ring][kKinds] blocks of kBlock bytes
         size_t cap = 0;
-        Geo geo[8][10];                             // per chain and kind
+        Geo geo[8][12];                             // per chain and kind
         uint64_t last_use[8] = {};                  // index of the last join packet after a use, per chain (+1)
         uint64_t stamp = 0;
     };
-    // kinds of launches a rollout is made of: the step of an even / odd step number (they differ in the snapshot buffers of a
-    // split rollout, and in their geometry under the test knob SSD_AQL_ALTERNATE); the reset; and for split rollouts the step
-    // launch that also renders the step before (AB) and the launch that only renders (B: the last step's observations)
-    // (kS / kR: the launches of a rollout that is not split -- step with observations, reset with observations; kRn: the reset of
-    // a split rollout, which renders nothing)
-    enum Kind { kS0 = 0, kS1 = 1, kR = 2, kRn = 3, kA0 = 4, kA1 = 5, kAB0 = 6, kAB1 = 7, kB0 = 8, kB1 = 9, kKinds = 10 };
-    uint8_t *snap_grid[2] = {};                     // split rollouts: [E][S] overlay snapshots, by step parity
-    uint32_t *snap_agents[2] = {};                  // ... and [E][N] agents
+    // Kinds of launches a rollout is made of, each for both ORIENTATIONS o of the handle's pair of state buffers (o = which
+    // of the two holds the current state; a launch of a split rollout reads buffer o and writes buffer 1 - o):
+    //   kS   step with observations, state in place (rollouts that are not split)     kR   reset with observations, in place
+    //   kRn  reset that renders nothing (inside a split rollout), in place
+    //   kA   the first step of a split rollout: env waves only                        kAB  env waves + renderer workgroups for the step before
+    //   kB   renderer workgroups only, for the step that produced buffer o (ends a split rollout, and precedes a reset inside one)
+    enum Kind { kS = 0, kR = 1, kRn = 2, kA = 3, kAB = 4, kB = 5, kKindsPerO = 6, kKinds = 12 };
+    uint8_t *world_buf[2] = {};                     // split rollouts: the pair of state buffers ([0]: the handle's original ones)
+    uint32_t *agents_buf[2] = {};
+    uint32_t *beam_list[2] = {};                    // [E][64] beam marks left by a launch of orientation o
+    uint8_t *snap_grid[2] = {};                     // [E][S] overlay snapshot left by a launch of orientation o (rare steps)
     static constexpr int kSets = 4;
     static constexpr size_t kBlock = 512;           // >= sizeof(ssd::KernArgs), a multiple of 64
     Set sets[kSets];
@@ -708,7 +712,11 @@ static void aql_teardown(ssd_env *env) {
     if (A.join_counter) (void)hipFree(A.join_counter);
     ssd::aql::host_kernarg_free(A.flag_kernarg);
     for (auto &st : A.sets) if (st.dev) (void)hipFree(st.dev);
-    for (int i = 0; i < 2; ++i) { if (A.snap_grid[i]) (void)hipFree(A.snap_grid[i]); if (A.snap_agents[i]) (void)hipFree(A.snap_agents[i]); }
+    // (of the state pair, world_buf[0] / agents_buf[0] are the handle's original allocations: freed with env->allocs; if the
+    // current state sits in the other pair, ssd_destroy frees whichever pointers env->p does not hold)
+    for (int i = 0; i < 2; ++i) { if (A.snap_grid[i]) (void)hipFree(A.snap_grid[i]); if (A.beam_list[i]) (void)hipFree(A.beam_list[i]); }
+    if (A.world_buf[1]) (void)hipFree(A.world_buf[1]);
+    if (A.agents_buf[1]) (void)hipFree(A.agents_buf[1]);
     env->aql.reset();
 }
 
@@ -776,14 +784,18 @@ static AqlState::Set *aql_set(ssd_env *env, const AqlState::Key &key, int chains
         if (hipMalloc(&ptr, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         st.dev = static_cast<uint8_t *>(ptr); st.cap = need;
     }
-    if (key.split && !A.snap_grid[0]) {                 // the snapshot buffers of split rollouts, once per handle
+    if (key.split && !A.world_buf[1]) {                 // the second state buffers and the render side buffers, once per handle
+        void *w = nullptr, *ag = nullptr;
+        if (hipMalloc(&w, (size_t)env->E * env->S) != hipSuccess || hipMalloc(&ag, (size_t)env->E * (env->N ? env->N : 1) * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        A.world_buf[0] = env->p.world; A.agents_buf[0] = env->p.agents;
+        A.world_buf[1] = static_cast<uint8_t *>(w); A.agents_buf[1] = static_cast<uint32_t *>(ag);
         for (int i = 0; i < 2; ++i) {
-            void *g = nullptr, *a = nullptr;
-            if (hipMalloc(&g, (size_t)env->E * env->S) != hipSuccess || hipMalloc(&a, (size_t)env->E * (env->N ? env->N : 1) * 4) != hipSuccess) {
-                (void)hipGetLastError();
-                return nullptr;
-            }
-            A.snap_grid[i] = static_cast<uint8_t *>(g); A.snap_agents[i] = static_cast<uint32_t *>(a);
+            void *g = nullptr, *bl = nullptr;
+            if (hipMalloc(&g, (size_t)env->E * env->S) != hipSuccess || hipMalloc(&bl, (size_t)env->E * 64 * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            A.snap_grid[i] = static_cast<uint8_t *>(g); A.beam_list[i] = static_cast<uint32_t *>(bl);
         }
     }
     std::vector<uint8_t> host(need, 0);
@@ -791,35 +803,36 @@ static AqlState::Set *aql_set(ssd_env *env, const AqlState::Key &key, int chains
         ChainCursor cur = chain_cursor(env, jobs[c]);
         for (int r = 0; r < key.ring; ++r)
             for (int kind = 0; kind < kKinds; ++kind) {
-                const bool only_b = kind == AqlState::kB0 || kind == AqlState::kB1;
-                const bool with_b = only_b || kind == AqlState::kAB0 || kind == AqlState::kAB1;
-                const bool split_kind = kind >= AqlState::kRn;
+                const int o = kind / AqlState::kKindsPerO, base = kind % AqlState::kKindsPerO;
+                const bool split_kind = base >= AqlState::kRn;
                 if (split_kind && !key.split) continue;
-                // parity of the step the launch COMPUTES (kB: of the step it renders)
-                const int parity = (kind == AqlState::kS1 || kind == AqlState::kA1 || kind == AqlState::kAB1 || kind == AqlState::kB1) ? 1 : 0;
+                if (!key.split && o == 1) continue;              // (without the pair there is one orientation)
                 Params p = cur.p;
+                if (key.split) { p.world = A.world_buf[o]; p.agents = A.agents_buf[o]; }     // the launch reads buffer o
                 p.obs = cur.obs ? cur.obs + (size_t)r * cur.ob : nullptr;
-                // (test knob: odd steps' launches use the other geometry)
-                p.coherent = key.coherent ? ((key.coherent == 2 && parity == 1) ? 2u : 1u) : 0u;
-                if (kind == AqlState::kR || kind == AqlState::kRn) {
+                // (test knob: launches of orientation 1 use the other geometry)
+                p.coherent = key.coherent ? ((key.coherent == 2 && o == 1) ? 2u : 1u) : 0u;
+                if (base == AqlState::kR || base == AqlState::kRn) {
                     p.mode = ssd::kModeReset; p.rotate = 0; p.num_actions_random = 0; p.rew = nullptr; p.done = nullptr;
                     // (every reset of a rollout is followed by a step that writes the same observation slot)
-                    if (kind == AqlState::kRn) p.obs = nullptr;
+                    if (base == AqlState::kRn) p.obs = nullptr;
                 } else {
                     p.mode = ssd::kModeStep; p.rotate = 1; p.num_actions_random = cur.num_actions;
                     p.rew = cur.rew ? cur.rew + (size_t)r * cur.en : nullptr; p.done = cur.done ? cur.done + (size_t)r * cur.en : nullptr;
-                    if (split_kind) {
-                        // the envs' waves leave a snapshot in buffer `parity`; the renderer workgroups of an AB launch render the
-                        // step before (the other buffer) into the ring slot before this one, those of a B launch this step's
+                    if (base >= AqlState::kA) {
+                        // env waves: read buffer o, write buffer 1 - o, leave their beam marks in list o.  Renderer workgroups of
+                        // a kAB launch: the step before produced buffer o (a launch of orientation 1 - o: its marks are in list
+                        // 1 - o), its observations go to the ring slot before this one; of a kB launch: the same for THIS slot.
                         uint8_t *obs_r = p.obs;
                         uint8_t *obs_prev = cur.obs ? cur.obs + (size_t)((r + key.ring - 1) % key.ring) * cur.ob : nullptr;
                         p.obs = nullptr;
-                        p.snap_mode = 1; p.snap = A.snap_grid[parity]; p.snap_agents = A.snap_agents[parity];
-                        if (with_b) {
-                            const int src = only_b ? parity : 1 - parity;
-                            p.snap_mode = only_b ? (2 | 4) : (1 | 2);
-                            p.snap_in = A.snap_grid[src]; p.snap_in_agents = A.snap_agents[src];
-                            p.obs_b = only_b ? obs_r : obs_prev;
+                        p.snap_mode = 1;
+                        p.world_out = A.world_buf[1 - o]; p.agents_out = A.agents_buf[1 - o];
+                        p.beam_list = A.beam_list[o]; p.snap = A.snap_grid[o];
+                        if (base != AqlState::kA) {
+                            p.snap_mode = base == AqlState::kB ? (2 | 4) : (1 | 2);
+                            p.beam_list_in = A.beam_list[1 - o]; p.snap_in = A.snap_grid[1 - o];
+                            p.obs_b = base == AqlState::kB ? obs_r : obs_prev;
                         }
                     }
                 }
@@ -873,6 +886,8 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     static const int env_split = [] { const char *v = getenv("SSD_AQL_SPLIT"); return v ? atoi(v) : 1; }();
     key.split = (coherent && env_split != 0 && j0.obs != nullptr && per_launch <= 2304) ? 1 : 0;   // (the argument set holds both forms' launches)
     const bool split = key.split && j0.n_steps >= 4;
+    // (a split set holds its launches for both orientations of the state pair; any other set names the buffer that is current now)
+    key.world = key.split ? nullptr : env->p.world;
     env->last_path |= SSD_PATH_AQL | (coherent ? SSD_PATH_COHERENT : 0) | (split ? SSD_PATH_SPLIT : 0);
     if ((size_t)chains * j0.ring > 2048) return 1;                     // (argument blocks: 10 x 512 B per chain and slot)
     AqlState::Set *st = aql_set(env, key, chains, jobs);
@@ -925,19 +940,30 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
         ssd::aql::dispatch(A.q[c], g.k, g.grid_x, g.block_x, g.lds, st->dev + (((size_t)c * ring + r) * kKinds + kind) * AqlState::kBlock,
                            barrier, acq, rel);
     };
+    // orientation: which buffer of the pair holds the current state (always 0 until the first split rollout of the handle)
+    int o = (A.world_buf[1] && env->p.world == A.world_buf[1]) ? 1 : 0;
+    const int KO = AqlState::kKindsPerO;
+    bool pending = false;                                 // a step's observations are still to be rendered (split rollouts)
+    size_t r_prev = 0;
     for (int k = 0; k < j0.n_steps; ++k) {
         const size_t r = (size_t)((step0 + k) % ring);
-        const int parity = (step0 + k) & 1;
         const bool reset = reset_every > 0 && (step0 + k) % reset_every == 0;
         for (int c = 0; c < chains; ++c) {
             const int acq = k == 0 ? 1 : kAcq;                                 // (the call's first launch of the chain)
-            if (reset) put(c, r, split ? AqlState::kRn : AqlState::kR, true, acq, kRel);
-            const int kind = !split ? (parity ? AqlState::kS1 : AqlState::kS0)
-                                    : k > 0 ? (parity ? AqlState::kAB1 : AqlState::kAB0) : (parity ? AqlState::kA1 : AqlState::kA0);
-            put(c, r, kind, true, reset ? kAcq : acq, kRel);
-            if (split && k == j0.n_steps - 1) put(c, r, parity ? AqlState::kB1 : AqlState::kB0, true, kAcq, kRel);
+            if (reset) {
+                // (a reset works in place: the step before it must have been rendered from that buffer first)
+                if (split && pending) put(c, r_prev, o * KO + AqlState::kB, true, kAcq, kRel);
+                put(c, r, o * KO + (split ? AqlState::kRn : AqlState::kR), true, acq, kRel);
+            }
+            const int base = !split ? AqlState::kS : (pending && !reset) ? AqlState::kAB : AqlState::kA;
+            put(c, r, o * KO + base, true, reset ? kAcq : acq, kRel);
+            if (split && k == j0.n_steps - 1) put(c, r, (1 - o) * KO + AqlState::kB, true, kAcq, kRel);   // (renders the buffer this step wrote)
             ssd::aql::ring(A.q[c]);
         }
+        if (split) { o = 1 - o; pending = true; r_prev = r; }
+    }
+    if (split) {                                          // the current state now sits in buffer o
+        env->p.world = A.world_buf[o]; env->p.agents = A.agents_buf[o];
     }
     // JOIN: every chain ends by bumping the join counter; a one-wave kernel on the caller's stream sleeps until all have
     if (sync_mode) {

@@ -76,14 +76,17 @@ struct Params {
     uint32_t pipe_seq;
     uint32_t coherent;             // the step launch moves state and outputs with agent-scope (sc1) accesses only (kernel: PIPE = 2); set by
                                    // the library's own dispatch path for the map-specific uint8 kernels (ssd_aql.hip)
-    // split rollouts (bits): 1 = the envs' waves write their overlay and agents to `snap` / `snap_agents` instead of rendering
-    // observations; 2 = the launch carries renderer workgroups (behind its first blocks_a) that render the previous step's
-    // observations from `snap_in` / `snap_in_agents` into `obs_b`; 4 = renderer workgroups only
+    // split rollouts (bits): 1 = the envs' waves do not render: they write grid and agents to `world_out` / `agents_out` (the other
+    // buffer of the pair), this step's beam marks to `beam_list` (and, for the rare step whose marks are not in registers, the
+    // overlay to `snap`); 2 = the launch carries renderer workgroups (behind its first blocks_a) that render the PREVIOUS step's
+    // observations from the launch's input state + `beam_list_in` (or `snap_in`) into `obs_b`; 4 = renderer workgroups only
     int32_t snap_mode, blocks_a;
-    uint8_t *snap;                 // [E][S]  overlay of the step (world <- agents <- beams)
-    uint32_t *snap_agents;         // [E][N]  cell | orient << 16 after the step
+    uint8_t *world_out;            // [E][S]  null: state is written in place
+    uint32_t *agents_out;          // [E][N]
+    uint32_t *beam_list;           // [E][64] cell | mark << 16 per lane of the step's beam trace; 0 none; 0xFFFFFFFF: see `snap`
+    const uint32_t *beam_list_in;  // the previous step's
+    uint8_t *snap;                 // [E][S]  overlay of the step (world <- agents <- beams), only after steps that could not list their marks
     const uint8_t *snap_in;        // the previous step's
-    const uint32_t *snap_in_agents;
     uint8_t *obs_b;                // [E][N][V][V][3]  where the renderer workgroups write
     uint32_t pipe_rotate;          // test knob (SSD_PIPE_ROTATE): shift the env -> workgroup mapping by this many workgroups per launch,
                                    // so that an env's consecutive steps run on different XCDs (workgroups go round-robin to XCDs)

@@ -348,7 +348,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     int blk = blockIdx.x;
     if constexpr (kFlag) blk = (int)((blockIdx.x + p.pipe_seq * p.pipe_rotate) % gridDim.x);   // (test knob; 0 = identity)
     // ---- renderer role (split rollouts): workgroups behind the launch's first p.blocks_a render the observations of the
-    //      PREVIOUS step of their envs from the snapshot that step's wave left (p.snap_in), nothing else ----
+    //      PREVIOUS step of their envs, nothing else.  What they show is the state this launch steps FROM (a_world / a_agents: the
+    //      env waves of the launch read the same lines and write elsewhere), overlaid with the agents' glyphs and the previous
+    //      step's beam marks (p.beam_list_in); or, for the rare step that left one, the overlay snapshot (p.snap_in) ----
     if constexpr (MODE == kModeStep && PIPE == 2 && STD && NA > 0 && NA % 5 == 0 && !F32 && FAST != 0) {
         if ((p.snap_mode & 2) && blk >= p.blocks_a) {
             const int eb = a_e_begin + (blk - p.blocks_a) * a_epb + wv;
@@ -360,12 +362,16 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             SSD_BSTAMP(10, __builtin_amdgcn_s_memrealtime());
             SSD_BSTAMP(0, __builtin_readcyclecounter());
             if (eb < a_E) {
+                typedef __attribute__((address_space(3))) const uint8_t lds_u8;
                 const uint32_t lut_a = a_lut[lane], lut_b = a_lut[lane + 64];
                 u32x4_t g0 = {0u, 0u, 0u, 0u};
-                const uint8_t *gsrc = p.snap_in + (size_t)eb * S;
+                const uint8_t *gsrc = a_world + (size_t)eb * S;
                 if (lane * 16 < S) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g0) : "v"(gsrc + lane * 16) : "memory");
                 uint32_t areg = 0;
-                if (lane < N) areg = __hip_atomic_load(p.snap_in_agents + (size_t)eb * N + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane < N) areg = __hip_atomic_load(a_agents + (size_t)eb * N + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (what the step left beside its state: bits 20 / 21 of agent 0's word -- a list of beam marks / an overlay
+                // snapshot; the list entry is fetched with the rest and ignored when the bit says there is none)
+                const uint32_t entry = __hip_atomic_load(p.beam_list_in + (size_t)eb * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 {   // the aprons of the layer: '0' (void) cells
                     const uint4 z = make_uint4(0x30303030u, 0x30303030u, 0x30303030u, 0x30303030u);
                     const int n0 = A0 >> 4, n1 = A1 >> 4;
@@ -374,16 +380,35 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 }
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0) : : "memory");
                 s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b;
+                const uint32_t flags = rfl(areg) >> 20;
+                const bool snapshot = (flags & 2u) != 0, marks = (flags & 1u) != 0;
+                if (snapshot) gsrc = p.snap_in + (size_t)eb * S;
+                if (snapshot && lane * 16 < S) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(g0) : "v"(gsrc + lane * 16) : "memory");
                 if (lane * 16 < S) *reinterpret_cast<uint4 *>(s_world + lane * 16) = make_uint4(g0.x, g0.y, g0.z, g0.w);
-                for (int i = lane * 16 + 1024; i < S; i += 1024) {
+                for (int i = lane * 16 + 1024; i < S; i += 1024) {             // maps above 1024 cells
                     u32x4_t gv;
                     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(gv) : "v"(gsrc + i) : "memory");
                     *reinterpret_cast<uint4 *>(s_world + i) = make_uint4(gv.x, gv.y, gv.z, gv.w);
                 }
                 wave_sync();
-                SSD_BSTAMP(1, __builtin_readcyclecounter());                // snapshot loaded
-                typedef __attribute__((address_space(3))) const uint8_t lds_u8;
                 const uint32_t cellb = areg & 0xFFFFu, orientb = (areg >> 16) & 3u;
+                if (!snapshot) {
+                    // get_map_with_agents (map_env.py:280-302): agents in index order -- the highest index on a cell shows --
+                    // then the beams over them
+                    const uint64_t agents_m = N >= 64 ? ~0ull : bit((uint32_t)N) - 1;
+                    uint64_t highest = 0;
+                    for (int j = 0; j < N; ++j) {
+                        const uint64_t here = ballot(cellb == rl(cellb, j)) & agents_m;
+                        highest |= ((here >> j) >> 1) ? 0ull : bit(j);
+                    }
+                    if (__builtin_amdgcn_inverse_ballot_w64(highest & agents_m)) s_world[cellb] = agent_glyph((uint32_t)lane);
+                    wave_sync();
+                    if (marks) {
+                        if (entry) s_world[entry & 0xFFFFu] = (uint8_t)(entry >> 16);
+                        wave_sync();
+                    }
+                }
+                SSD_BSTAMP(1, __builtin_readcyclecounter());                // layer ready
                 const uint32_t kq = orientb == 2 ? 0u : orientb == 0 ? 1u : orientb == 3 ? 2u : 3u;     // rotate_view: UP 0, LEFT 1, DOWN 2, RIGHT 3
                 const uint32_t s0 = (uint32_t)((int)cellb - 7 * (WP + 1) + (kq >= 2 ? 14 * (WP + 1) : 0));
                 render_views_std<NA>(lane, WP, kq, s0, (uint32_t)(uintptr_t)(lds_u8 *)s_world, s_lut, p.obs_b + (size_t)eb * N * 675, true);
@@ -533,9 +558,14 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // the last spawn pass used, ssd_get_waste_count): a step only changes it by the cells its CLEAN beams clean and the
         // one waste cell it may spawn, so compute_permitted_area (cleanup.py:173-179) need not recount the grid.
         uint32_t waste_cur = GAME == 1 ? rfl(hdr.w) >> 16 : 0u;
-        auto write_state = [&]() {
+        auto write_state = [&](const uint32_t render_flags) {
             uint8_t *gw = a_world + (size_t)e * S;
             if constexpr (kCoh) {
+                // (split rollouts: grid and agents go to the other buffer of the pair, this launch's renderer waves read the input)
+                uint32_t *ga = a_agents;
+                if (p.world_out) { gw = p.world_out + (size_t)e * S; ga = p.agents_out; }
+                // (render_flags, split rollouts: what the renderer will find beside this state -- bits 20 / 21 of agent 0's
+                // word: a list of beam marks / an overlay snapshot; readers of the word take bits 0..17)
                 auto cstore = [](uint32_t *ptr, uint32_t v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
                 for (int i = lane * 16; i < S; i += 64 * 16) {
                     const uint4 v4 = *reinterpret_cast<const uint4 *>(s_world + i);
@@ -543,7 +573,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     // one 16-byte write-through store (the s_nop: a store of more than 64 bits reads its data registers late)
                     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(gw + i), "v"(v) : "memory");
                 }
-                if (is_agent) cstore(a_agents + (size_t)e * N + lane, cell | (orient << 16));
+                if (is_agent) cstore(ga + (size_t)e * N + lane, cell | (orient << 16) | (lane == 0 ? render_flags : 0u));
                 if (lane < 4) cstore(reinterpret_cast<uint32_t *>(a_hdr + e) + lane,
                                      lane == 0 ? key : lane == 1 ? t : lane == 2 ? episode : (waste_last | (waste_cur << 16)));
                 if (status && lane == 0) atomicOr(p.status, status);
@@ -1190,7 +1220,14 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 // ---- write the env back (grid, agents, header: a rollout does that once, after its last step) and
                 //      this step's rewards and dones ----
                 waste_last = waste_count;
-                if (!roll) write_state();
+                if (!roll) {
+                    uint32_t render_flags = 0;
+                    if constexpr (stepping && PIPE == 2) {
+                        if ((p.snap_mode & 1) && is_step)
+                            render_flags = (!keep_beams && beams_in_regs) ? (ballot(b_cov) ? 1u << 20 : 0u) : 1u << 21;
+                    }
+                    write_state(render_flags);
+                }
                 if (is_agent && is_step) {
                     // compute_reward (:208); get_done -> False (:209); with a horizon set, the episode ends after `horizon` steps
                     const uint8_t dn = (p.horizon > 0 && t >= (uint32_t)p.horizon) ? 1 : 0;
@@ -1211,7 +1248,27 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             //      world are in registers -- agents' cells, beam cells -- so two predicated byte stores do it (a rollout copies
             //      the layer first, 16 B per lane); otherwise the three layers are merged 4 cells per op. ----
             const bool patch = is_step && !keep_beams && beams_in_regs;
-            if (patch && !SSD_SKIP(5)) {
+            // Split rollouts (ssd_capi.hip): the env's wave does not render observations -- extra waves of the NEXT step's launch
+            // do (the renderer role above), from the very state that launch steps from (this wave writes its state into the other
+            // of two buffers, the next launch reads it, nobody writes it meanwhile) plus what the state does not hold: this step's
+            // beam marks, one list entry per lane (cell | mark << 16; 0: none).  The overlay is then not built here at all.  Rare
+            // steps whose beams did not stay in registers (several shooter groups, CLEAN conflicts) build the overlay as usual and
+            // leave it in a snapshot instead; entry 0xFFFFFFFF tells the renderer so.  The observation phase (1.2 us of a 5.7 us
+            // step) thereby leaves the chain of dependent launches.
+            bool leave_overlay = false;                       // wave-uniform
+            if constexpr (stepping && PIPE == 2) {
+                if ((p.snap_mode & 1) && is_step) {
+                    leave_overlay = patch;
+                    // (which of the two the step left is said by two spare bits of agent 0's state word, written with the state
+                    // above; the list is only written when there is a mark at all.  One dword per lane: staging it through LDS
+                    // for 16-byte stores cost more on this wave's path than it saved, 5.29 against 5.15 us per step)
+                    if (patch && ballot(b_cov))
+                        __hip_atomic_store(p.beam_list + (size_t)e * 64 + lane, b_cov ? ((uint32_t)b_idx | (b_chr << 16)) : 0u,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (leave_overlay) {
+            } else if (patch && !SSD_SKIP(5)) {
                 if (roll)
                     for (int i = lane * 16; i < S; i += 64 * 16)
                         *reinterpret_cast<uint4 *>(s_view + i) = *reinterpret_cast<const uint4 *>(s_world + i);
@@ -1228,19 +1285,14 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 *reinterpret_cast<uint32_t *>(s_view + i) = v;
             }
             wave_sync();
-            // Split rollouts (ssd_capi.hip): the env's wave does not render observations; it leaves the overlay it has just
-            // built -- world <- agents <- beams -- and the agents' cells and rotations in a snapshot (write-through), and extra
-            // waves of the NEXT step's launch render from it (the renderer role below) while that step is being computed.  The
-            // observation phase (1.2 us of a 5.7 us step) thereby leaves the chain of dependent launches.
             if constexpr (stepping && PIPE == 2) {
-                if ((p.snap_mode & 1) && is_step) {
+                if ((p.snap_mode & 1) && is_step && !patch) {                 // (the rare form: the overlay as a snapshot)
                     uint8_t *sg = p.snap + (size_t)e * S;
                     for (int i = lane * 16; i < S; i += 64 * 16) {
                         const uint4 v4 = *reinterpret_cast<const uint4 *>(s_view + i);
                         const u32x4_t v = {v4.x, v4.y, v4.z, v4.w};
                         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(sg + i), "v"(v) : "memory");
                     }
-                    if (is_agent) __hip_atomic_store(p.snap_agents + (size_t)e * N + lane, cell | (orient << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             SSD_STAMP(7);   // overlay built
@@ -1421,7 +1473,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             if (to_reset >= 0) to_reset = (to_reset == 0 ? p.reset_every : to_reset) - 1;
             in_reset = to_reset == 0;
         }
-        if (roll) write_state();
+        if (roll) write_state(0u);
         // (the launch that follows in the chain starts when this one has ended: every store of this wave has landed by then)
 #ifndef SSD_EXP_NO_END_WAIT
         if constexpr (PIPE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
