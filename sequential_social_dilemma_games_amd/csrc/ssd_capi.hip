@@ -78,7 +78,7 @@ struct AqlState {
         Key key;
         uint8_t *dev = nullptr;                     // [chains][ring][kKinds] blocks of kBlock bytes
         size_t cap = 0;
-        Geo geo[8][12];                             // per chain and kind
+        Geo geo[8][12];                             // per chain and kind (kKinds: asserted below)
         uint64_t last_use[8] = {};                  // index of the last join packet after a use, per chain (+1)
         uint64_t stamp = 0;
     };
@@ -89,6 +89,7 @@ struct AqlState {
     //   kA   the first step of a split rollout: env waves only                        kAB  env waves + renderer workgroups for the step before
     //   kB   renderer workgroups only, for the step that produced buffer o (ends a split rollout, and precedes a reset inside one)
     enum Kind { kS = 0, kR = 1, kRn = 2, kA = 3, kAB = 4, kB = 5, kKindsPerO = 6, kKinds = 12 };
+    static_assert(sizeof(Set::geo[0]) / sizeof(Geo) == kKinds, "Set::geo holds one entry per kind");
     uint8_t *world_buf[2] = {};                     // split rollouts: the pair of state buffers ([0]: the handle's original ones)
     uint32_t *agents_buf[2] = {};
     uint32_t *beam_list[2] = {};                    // [E][64] beam marks left by a launch of orientation o
@@ -958,6 +959,9 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
             const int base = !split ? AqlState::kS : (pending && !reset) ? AqlState::kAB : AqlState::kA;
             put(c, r, o * KO + base, true, reset ? kAcq : acq, kRel);
             if (split && k == j0.n_steps - 1) put(c, r, (1 - o) * KO + AqlState::kB, true, kAcq, kRel);   // (renders the buffer this step wrote)
+            // (tried: the call's last step rendering itself, its renderer waves in the env's own workgroup behind a barrier -- with
+            // a one-slot ring both write the same bytes -- instead of the renderer-only launch: 6.60 against 6.62 us per step of
+            // a 20-step call, no gain)
             ssd::aql::ring(A.q[c]);
         }
         if (split) { o = 1 - o; pending = true; r_prev = r; }
@@ -1360,6 +1364,12 @@ int ssd_debug_set_skip(ssd_env *env, uint32_t mask) {
     if (!env) return SSD_E_INVALID;
     env->p.dbg_skip = mask;
     return SSD_OK;
+}
+// Diagnostic library only: a one-wave kernel writes the stamps' 100 MHz clock into a host-visible word `iters` times.
+int ssd_debug_clock(ssd_env *env, void *host_word, int iters, void *stream) {
+    if (!env || !host_word) return SSD_E_INVALID;
+    ssd::launch_clock_kernel(static_cast<unsigned long long *>(host_word), iters, stream);
+    return hipGetLastError() == hipSuccess ? SSD_OK : SSD_E_DEVICE;
 }
 // Diagnostic library only (make stamps): device buffer [E][16] u64 that the kernel fills with cycle stamps.
 int ssd_debug_set_stamps(ssd_env *env, void *dev_ptr) {

@@ -123,6 +123,9 @@ void launch(const Launch &L, void *stream);            // hipLaunchKernel of a r
 void launch(const Params &p, int game, void *stream);
 const void *flag_kernel_fn();                          // ssd_flag_kernel's host stub (AQL join)
 void launch_wait_counter_kernel(const unsigned long long *counter, unsigned long long target, const uint32_t *abort, void *stream);
+#ifdef SSD_STAMPS
+void launch_clock_kernel(unsigned long long *out, int iters, void *stream);
+#endif
 void launch_signal_kernel(long long *signal_value, void *stream);   // AQL fork: zero an HSA signal from a HIP stream
 void launch_render_full(const Params &p, int e0, int count, uint8_t *rgb_dev, void *stream);
 

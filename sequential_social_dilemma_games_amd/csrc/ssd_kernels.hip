@@ -1633,6 +1633,20 @@ __global__ void ssd_wait_counter_kernel(const unsigned long long *counter, unsig
 __global__ void ssd_signal_kernel(long long *signal_value) {
     if (threadIdx.x == 0) __hip_atomic_store(signal_value, 0ll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+#ifdef SSD_STAMPS
+// Diagnostic library only: publishes the 100 MHz clock the stamps use to a host-visible word, over and over, so that a tool
+// can place the stamps on the host's time axis (tools/call_timeline.py).
+__global__ void ssd_clock_kernel(unsigned long long *out, int iters) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < iters; ++i) {
+        __hip_atomic_store(out, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+void launch_clock_kernel(unsigned long long *out, int iters, void *stream) {
+    hipLaunchKernelGGL(ssd_clock_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), out, iters);
+}
+#endif
 const void *flag_kernel_fn() { return reinterpret_cast<const void *>(&ssd_flag_kernel); }
 void launch_wait_counter_kernel(const unsigned long long *counter, unsigned long long target, const uint32_t *abort, void *stream) {
     hipLaunchKernelGGL(ssd_wait_counter_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), counter, target, abort);
