@@ -349,10 +349,12 @@ def main():
     # resident in LDS / registers across its steps (SSD_ROLLOUT_FUSED).  Not part of `value`.
     fused_wall = fused_long_us = None
     if plain and not args.obs_f32:
+        eng.set_rollout_chains(0)                  # the library's own choice (one launch per GPU: no second stream to fork and join)
         fused_wall, _, _ = time_rollout(torch, eng, ring, args.steps, args.warmup, fused=True)
         if args.steps < 1000:
             fw, _, _ = time_rollout(torch, eng, ring, 1000, 0, step0=args.warmup + args.steps, fused=True)
             fused_long_us = fw * 1e6 / 1000
+        eng.set_rollout_chains(chains)
         if eng.status() != 0:
             raise SystemExit("device status word is non-zero")
     if dist is not None:

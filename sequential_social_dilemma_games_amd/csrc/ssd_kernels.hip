@@ -364,9 +364,14 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             if (eb < a_E) {
                 typedef __attribute__((address_space(3))) const uint8_t lds_u8;
                 const uint32_t lut_a = a_lut[lane], lut_b = a_lut[lane + 64];
-                u32x4_t g0 = {0u, 0u, 0u, 0u};
+                constexpr int kGridLoads = (fm.S + 1023) / 1024;       // the grid in pieces of 1 KiB, all fetched at once
+                u32x4_t g0[kGridLoads];
                 const uint8_t *gsrc = a_world + (size_t)eb * S;
-                if (lane * 16 < S) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g0) : "v"(gsrc + lane * 16) : "memory");
+#pragma unroll
+                for (int j = 0; j < kGridLoads; ++j) {
+                    g0[j] = u32x4_t{0u, 0u, 0u, 0u};
+                    if (lane * 16 + j * 1024 < S) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g0[j]) : "v"(gsrc + lane * 16 + j * 1024) : "memory");
+                }
                 uint32_t areg = 0;
                 if (lane < N) areg = __hip_atomic_load(a_agents + (size_t)eb * N + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // (what the step left beside its state: bits 20 / 21 of agent 0's word -- a list of beam marks / an overlay
@@ -378,18 +383,24 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     for (int i = lane; i < n0 + n1; i += 64)
                         *reinterpret_cast<uint4 *>(i < n0 ? s_world - A0 + i * 16 : s_world + S + (i - n0) * 16) = z;
                 }
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0) : : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0[0]) : : "memory");
+#pragma unroll
+                for (int j = 1; j < kGridLoads; ++j) asm volatile("" : "+v"(g0[j]));      // (not to be read before the wait)
                 s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b;
                 const uint32_t flags = rfl(areg) >> 20;
                 const bool snapshot = (flags & 2u) != 0, marks = (flags & 1u) != 0;
-                if (snapshot) gsrc = p.snap_in + (size_t)eb * S;
-                if (snapshot && lane * 16 < S) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(g0) : "v"(gsrc + lane * 16) : "memory");
-                if (lane * 16 < S) *reinterpret_cast<uint4 *>(s_world + lane * 16) = make_uint4(g0.x, g0.y, g0.z, g0.w);
-                for (int i = lane * 16 + 1024; i < S; i += 1024) {             // maps above 1024 cells
-                    u32x4_t gv;
-                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(gv) : "v"(gsrc + i) : "memory");
-                    *reinterpret_cast<uint4 *>(s_world + i) = make_uint4(gv.x, gv.y, gv.z, gv.w);
+                if (snapshot) {                                         // (rare: the overlay as the step left it, instead of the state)
+                    gsrc = p.snap_in + (size_t)eb * S;
+#pragma unroll
+                    for (int j = 0; j < kGridLoads; ++j)
+                        if (lane * 16 + j * 1024 < S) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g0[j]) : "v"(gsrc + lane * 16 + j * 1024) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0[0]) : : "memory");
+#pragma unroll
+                    for (int j = 1; j < kGridLoads; ++j) asm volatile("" : "+v"(g0[j]));
                 }
+#pragma unroll
+                for (int j = 0; j < kGridLoads; ++j)
+                    if (lane * 16 + j * 1024 < S) *reinterpret_cast<uint4 *>(s_world + lane * 16 + j * 1024) = make_uint4(g0[j].x, g0[j].y, g0[j].z, g0[j].w);
                 wave_sync();
                 const uint32_t cellb = areg & 0xFFFFu, orientb = (areg >> 16) & 3u;
                 if (!snapshot) {
@@ -444,6 +455,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     }
     if (active) {
         const bool is_agent = lane < N;
+#ifdef SSD_EXP_STAGGER   // experiment: the waves of a rollout launch start out of phase (quarter periods) instead of in step
+        if (roll) for (int i = 0; i < (e & 3); ++i) __builtin_amdgcn_s_sleep(SSD_EXP_STAGGER);
+#endif
         // ---- prologue: every global load of the env is issued before the first use, so the HBM / L2
         //      latency is paid once.  First the loads whose addresses come from the preloaded arguments alone (hdr, agents,
         //      the first 1 KiB of the grid = the whole grid of the shipped maps, the colour table, the apple list), then
@@ -472,16 +486,25 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         uint32_t ord_in = 0xFFu;
         if (mode != kModeReset && is_agent) areg = cload(a_agents + (size_t)e * N + lane);
         const uint8_t *gsrc = mode == kModeReset ? p.reset_world : a_world + (size_t)e * S;
-        uint4 w0 = make_uint4(0, 0, 0, 0), b0 = make_uint4(0, 0, 0, 0);
-        u32x4_t w0c = {0u, 0u, 0u, 0u};                                 // (coherent variants: the asm load's destination)
-        if (lane * 16 < S) {
-            if (kCoh) {
-                w0c = cload16(gsrc + lane * 16);
-            } else {
-                w0 = *reinterpret_cast<const uint4 *>(gsrc + lane * 16);
+        // (a known map's grid is kGridLoads pieces of 1 KiB, 16 bytes per lane each: ALL of them go out here -- fetched one after
+        // the other behind the first, as the general kernel's loop below does, every piece past the first is another round trip
+        // to memory on the wave's path: 25 x 38 Harvest 2 pieces, 48 x 36 Cleanup 3)
+        constexpr int kGridLoads = FAST ? (fm.S + 1023) / 1024 : 1;
+        uint4 w0[kGridLoads], b0 = make_uint4(0, 0, 0, 0);
+        u32x4_t w0c[kGridLoads];                                        // (coherent variants: the asm loads' destinations)
+#pragma unroll
+        for (int j = 0; j < kGridLoads; ++j) {
+            w0[j] = make_uint4(0, 0, 0, 0);
+            w0c[j] = u32x4_t{0u, 0u, 0u, 0u};
+            if (lane * 16 + j * 1024 < S) {
+                if (kCoh) {
+                    w0c[j] = cload16(gsrc + lane * 16 + j * 1024);
+                } else {
+                    w0[j] = *reinterpret_cast<const uint4 *>(gsrc + lane * 16 + j * 1024);
+                }
             }
-            if (mode == kModeObserve && keep_beams) b0 = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + lane * 16);
         }
+        if (lane * 16 < S && mode == kModeObserve && keep_beams) b0 = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + lane * 16);
         // glyph -> RGB table of the observation phase, one copy per wave
         // (a launch that renders nothing -- the env waves of a split rollout, a reset inside one -- needs no colour table)
         uint32_t lut_a = 0, lut_b = 0;
@@ -514,9 +537,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             wlist[j] = 0u;
             if (GAME == 1 && 64 * j < n_waste) wlist[j] = (mode != kModeObserve && idx < n_waste) ? p.waste_cells[idx] : 0u;
         }
-        if (kCoh) {                                                      // (the asm load above)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0c) : : "memory");
-            w0 = make_uint4(w0c.x, w0c.y, w0c.z, w0c.w);
+        if (kCoh) {                                                      // (the asm loads above)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0c[0]) : : "memory");
+#pragma unroll
+            for (int j = 0; j < kGridLoads; ++j) {
+                if (j) asm volatile("" : "+v"(w0c[j]));                  // (not to be read before the wait)
+                w0[j] = make_uint4(w0c[j].x, w0c[j].y, w0c[j].z, w0c[j].w);
+            }
         }
         uint32_t key = rfl(hdr.x), t = rfl(hdr.y), episode = rfl(hdr.z);
         if (a_obs) { s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b; }
@@ -525,18 +552,20 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         uint32_t cell = areg & 0xFFFFu, orient = mode == kModeReset ? 2u : (areg >> 16) & 3u;   // lane = agent index
         int rew = 0;
         // grid -> LDS (16 B per lane); beam and occupancy layers start empty
-        if (lane * 16 < S) {
-            *reinterpret_cast<uint4 *>(s_world + lane * 16) = w0;
-            *reinterpret_cast<uint4 *>(s_beam + lane * 16) = b0;
-            *reinterpret_cast<uint4 *>(s_occ + lane * 16) = make_uint4(0, 0, 0, 0);
-        }
+#pragma unroll
+        for (int j = 0; j < kGridLoads; ++j)
+            if (lane * 16 + j * 1024 < S) {
+                *reinterpret_cast<uint4 *>(s_world + lane * 16 + j * 1024) = w0[j];
+                *reinterpret_cast<uint4 *>(s_beam + lane * 16 + j * 1024) = j == 0 ? b0 : make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4 *>(s_occ + lane * 16 + j * 1024) = make_uint4(0, 0, 0, 0);
+            }
         if (a_obs) {                                         // the aprons of the layer the observations read: '0' (void) cells
             const uint4 z = make_uint4(0x30303030u, 0x30303030u, 0x30303030u, 0x30303030u);
             const int n0 = A0 >> 4, n1 = A1 >> 4;
             for (int i = lane; i < n0 + n1; i += 64)
                 *reinterpret_cast<uint4 *>(i < n0 ? s_view - A0 + i * 16 : s_view + S + (i - n0) * 16) = z;
         }
-        for (int i = lane * 16 + 1024; i < S; i += 1024) {   // maps above 1024 cells
+        for (int i = lane * 16 + 1024 * kGridLoads; i < S; i += 1024) {   // (general kernel) maps above 1024 cells
             uint4 bv = make_uint4(0, 0, 0, 0);
             if (mode == kModeObserve && keep_beams) bv = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + i);
             if (kCoh) {
