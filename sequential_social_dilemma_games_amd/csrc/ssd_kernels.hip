@@ -206,6 +206,8 @@ __device__ __forceinline__ void render_views_std(const int lane, const int WP, c
                 d.x = __builtin_amdgcn_perm(px[u][1], px[u][0], 0x04020100u);   // r0 g0 b0 r1
                 d.y = __builtin_amdgcn_perm(px[u][2], px[u][1], 0x05040201u);   // g1 b1 r2 g2
                 d.z = __builtin_amdgcn_perm(px[u][3], px[u][2], 0x06050402u);   // b2 r3 g3 b3
+                // (measured with agent blocks 768 bytes apart instead -- every store then covers whole 128-byte lines: 5.30 against
+                // 5.33 us per step; the partly written lines at the blocks' ends are not what bounds the stores)
                 store12_wt(out_env + (size_t)(ag0 + u) * VV * 3, off3, d, wt);
             }
         }
@@ -324,7 +326,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     // List registers per lane (64 * kLR entries of a static cell list live in registers, the rest is read from memory when
     // needed).  Measured: 8 pays for Cleanup's long lists (48x36 map: 412 apple / 476 waste points, -4 % per step, -10 %
     // fused), 3 is better for Harvest (25x38 map, 262 apple points: 8 costs +4 % per step).
-    constexpr int kLR = GAME == 1 ? kListRegsCleanup : kListRegsHarvest;
+    // The enlarged Harvest map's own kernel takes 4: its 252 points then all sit in registers and the usual respawn takes its
+    // compact form (one stencil + draw per lane instead of four): 6.49 -> 6.05 us per 4096-env step.
+    constexpr int kLR = GAME == 1 ? kListRegsCleanup : (FAST == 2 ? 4 : kListRegsHarvest);
     // sizes of the map's cell lists (FAST: the shipped maps' -- launch_game() checks them): lets the compiler drop the
     // unused third list register of Cleanup's 103 apple / 119 waste points
     const int n_apple = FAST ? fm.n_apple : a_n_apple, n_waste = FAST ? fm.n_waste : p.n_waste;
@@ -352,6 +356,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     //      env waves of the launch read the same lines and write elsewhere), overlaid with the agents' glyphs and the previous
     //      step's beam marks (p.beam_list_in); or, for the rare step that left one, the overlay snapshot (p.snap_in) ----
     if constexpr (MODE == kModeStep && PIPE == 2 && STD && NA > 0 && NA % 5 == 0 && !F32 && FAST != 0) {
+        // (measured: the renderer workgroups FIRST in the grid: 6.44 against 5.33 us per step; renderer waves that start their work
+        // out of phase, by up to 0.3 / 0.7 us: 5.56 / 5.53 against 5.35 -- neither role of a launch has slack)
         if ((p.snap_mode & 2) && blk >= p.blocks_a) {
             const int eb = a_e_begin + (blk - p.blocks_a) * a_epb + wv;
 #ifdef SSD_STAMPS   // renderer waves stamp into the second half of the buffer: [E_total + env][16]
@@ -364,6 +370,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             if (eb < a_E) {
                 typedef __attribute__((address_space(3))) const uint8_t lds_u8;
                 const uint32_t lut_a = a_lut[lane], lut_b = a_lut[lane + 64];
+                // (the state was written through this very XCD's L2 a launch ago -- env and renderer workgroup numbers agree modulo
+                // 8 -- but reading it there needs the CU's L1 out of the way: a buffer_inv sc1 per wave makes the step 33 us;
+                // sc0 loads (L2, past L1 only in threadgroup-split mode) returned stale lines in the env waves)
                 constexpr int kGridLoads = (fm.S + 1023) / 1024;       // the grid in pieces of 1 KiB, all fetched at once
                 u32x4_t g0[kGridLoads];
                 const uint8_t *gsrc = a_world + (size_t)eb * S;
@@ -455,9 +464,6 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     }
     if (active) {
         const bool is_agent = lane < N;
-#ifdef SSD_EXP_STAGGER   // experiment: the waves of a rollout launch start out of phase (quarter periods) instead of in step
-        if (roll) for (int i = 0; i < (e & 3); ++i) __builtin_amdgcn_s_sleep(SSD_EXP_STAGGER);
-#endif
         // ---- prologue: every global load of the env is issued before the first use, so the HBM / L2
         //      latency is paid once.  First the loads whose addresses come from the preloaded arguments alone (hdr, agents,
         //      the first 1 KiB of the grid = the whole grid of the shipped maps, the colour table, the apple list), then
@@ -474,6 +480,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory");
             return v;
         };
+        // (coherent variants: lanes 0..3 fetch the header's four words.  The v_readlanes right behind the load make the wave
+        // wait for it before it issues the others -- two round trips to memory in a row.  Measured, not reasoned: reading the
+        // lanes out after the common wait shortens the wave by 0.2 us (diagnostic build: load phase 1605 -> 1138 cycles) and
+        // makes the 4096-env step SLOWER, 5.35 -> 5.53 us (Cleanup 5.79 -> 5.95; no difference at 1024 or 16 384 envs):
+        // with two chains of launches in flight the step is not the wave's latency alone, and the staggered loads suit it)
         uint4 hdr;
         if (kCoh) {
             const uint32_t hv = cload(reinterpret_cast<const uint32_t *>(a_hdr + e) + (lane & 3));
