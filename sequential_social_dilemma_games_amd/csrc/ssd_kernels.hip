@@ -761,6 +761,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     clashm |= (on_cell & ~bit(j)) | on_target;
                     dupm |= on_target;
                 }
+                // (1.75 % of the envs of a random-action Harvest step; upper bound of what a faster slow path could give -- every env
+                // taking the fast path, wrong results --: 5.13 against 5.35 us per 4096-env step; Cleanup: no difference)
                 const bool slow = (clashm & M) != 0;
                 SSD_NOTE(12, slow ? 1 : 0);
                 if (!slow) {

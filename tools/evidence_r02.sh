@@ -13,3 +13,8 @@ for g in harvest cleanup; do
   SSD_AQL_ALTERNATE=1 SSD_AQL_ALWAYS_FORK=1 python3 tools/soak_parity.py $g 4096 3000 250 chains 2>&1 | grep -v amdgpu.ids | tee $D/soak_${g}_chains_alternate.log | tail -2
   python3 tools/soak_parity.py $g 4096 3000 250 fused 2>&1 | grep -v amdgpu.ids | tee $D/soak_${g}_fused.log | tail -2
 done
+# ... and the enlarged maps' own kernels (BASELINE.json's 25x38 label; configs[4]'s per-GPU share)
+python3 tools/soak_parity.py harvest25x38 4096 2000 250 chains 2>&1 | grep -v amdgpu.ids | tee $D/soak_harvest25x38_chains.log | tail -2
+python3 tools/soak_parity.py cleanup48x36 2048 2000 250 chains 2>&1 | grep -v amdgpu.ids | tee $D/soak_cleanup48x36_chains.log | tail -2
+SSD_AQL_ALTERNATE=1 python3 tools/soak_parity.py cleanup48x36 2048 1000 250 chains 2>&1 | grep -v amdgpu.ids | tee $D/soak_cleanup48x36_chains_alternate.log | tail -2
+python3 tools/soak_parity.py harvest25x38 4096 1000 250 fused 2>&1 | grep -v amdgpu.ids | tee $D/soak_harvest25x38_fused.log | tail -2

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long-run parity soak (GPU box): E envs, T random-action steps with a reset every 1000 steps; every K steps the
 engine's full state (world, positions, orientations, counters) and the step's observations / rewards are compared
-with the C oracle's.  python tools/soak_parity.py [harvest|cleanup] [E] [T] [K] [step|chains|fused]
+with the C oracle's.  python tools/soak_parity.py [harvest|cleanup|harvest25x38|cleanup48x36] [E] [T] [K] [step|chains|fused]
 (step: one step_random call per step; chains: ssd_rollout_random with 2 chains between checkpoints; fused: the rollout
 kernel, one launch between checkpoints)"""
 import os
@@ -20,14 +20,20 @@ from sequential_social_dilemma_games_amd.engine import VecEngine  # noqa: E402
 
 
 def main():
-    game = K.GAME_CLEANUP if (len(sys.argv) > 1 and sys.argv[1] == "cleanup") else K.GAME_HARVEST
+    which = sys.argv[1] if len(sys.argv) > 1 else "harvest"   # harvest | cleanup | harvest25x38 | cleanup48x36 (the enlarged maps, 5 / 10 agents)
+    game = K.GAME_CLEANUP if which.startswith("cleanup") else K.GAME_HARVEST
     E = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     T = int(sys.argv[3]) if len(sys.argv) > 3 else 4000
     Kc = int(sys.argv[4]) if len(sys.argv) > 4 else 50
     how = sys.argv[5] if len(sys.argv) > 5 else "step"
     amap = K.HARVEST_MAP if game == K.GAME_HARVEST else K.CLEANUP_MAP
-    eng = VecEngine(game, amap, num_envs=E, num_agents=5, seed=2024)
-    ora = pyoracle.Oracle(game, amap, E, 5, G.default_lut(), seed=2024)
+    n_agents = 5
+    if which == "harvest25x38":
+        amap = K.harvest_map_25x38()
+    elif which == "cleanup48x36":
+        amap, n_agents = K.cleanup_map_48x36(), 10
+    eng = VecEngine(game, amap, num_envs=E, num_agents=n_agents, seed=2024)
+    ora = pyoracle.Oracle(game, amap, E, n_agents, G.default_lut(), seed=2024)
     out = eng.alloc_outputs()
     ora.reset()
     if len(sys.argv) <= 5 or sys.argv[5] == "step":       # (the rollout calls reset at step 0 themselves: reset_every)
@@ -67,7 +73,7 @@ def main():
                 print("step %6d ok (%d checkpoints, %.0f s)" % (s + 1, checks, time.time() - t0), flush=True)
     assert eng.status() == 0
     print("soak ok (%s): %s, %d envs x %d steps = %.1f M env-steps, %d checkpoints bit-exact" %
-          (how, "cleanup" if game else "harvest", E, T, E * T / 1e6, checks))
+          (how, which, E, T, E * T / 1e6, checks))
 
 
 if __name__ == "__main__":
