@@ -133,6 +133,7 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // envs per launch, two launches in flight) the kernel is bandwidth-bound, L2 merging of the 12-byte pieces matters more than the final flush, and ordinary
 // stores win (65 536 envs: 53.6 vs 69.4 us).
 __device__ __forceinline__ void store12_wt(uint8_t *base, uint32_t off, u32x3_t d, bool wt) {
+    // (`sc1 nt`, non-temporal on top: 6.91 against 5.34 us per 4096-env step -- the stores then seem to bypass the memory-side cache)
     if (wt) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
     else asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
 }
