@@ -30,6 +30,14 @@ import subprocess
 import sys
 import time
 
+# A rank of a process group (RCCL).  The HIP runtime multiplexes its streams (torch's, RCCL's) onto at most GPU_MAX_HW_QUEUES hardware
+# queues (default 4), the library adds queues of its own, and beyond FOUR queues per process the hardware scheduler time-slices
+# them: a rollout call that follows an RCCL barrier then takes 320 us instead of 130 (measured under torch.distributed.run: 3 or
+# more here -> 16.2 us per step of a 20-step call, 1 or 2 -> 6.7).  With 2 for the runtime the library keeps to 2 of its own
+# (ssd_aql.hip, pool_size()).  Read by the runtime when it loads: set before torch is imported; an explicit setting wins.
+if "MASTER_PORT" in os.environ or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
@@ -127,8 +135,6 @@ def game_spec(name, agents=None):
     return game, amap, (n if agents is None else agents)
 
 
-def auto_chains(E, pipelined=False):
-    return 1 if pipelined or E < 2048 else 3 if 6144 <= E <= 24576 else 2    # (a pipelined chain overlaps its own launches)
 
 
 def time_rollout(torch, eng, ring, steps, warmup, step0=0, **kw):
@@ -161,9 +167,9 @@ def config_leg(torch, name, E, steps=400, warmup=50, obs_f32=False, pipelined=Fa
     out = eng.alloc_outputs(float32=obs_f32)
     ring = tuple(t.unsqueeze(0) for t in out) if ring_slots <= 1 else \
         tuple(torch.empty((ring_slots,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in out)
-    chains = auto_chains(E, pipelined)
-    eng.set_rollout_chains(chains)
+    eng.set_rollout_chains(0)                      # the library's own choice
     wall, dev_ms, _ = time_rollout(torch, eng, ring, steps, warmup, pipelined=pipelined)
+    chains = eng.rollout_path()["chains"]
     if eng.status() != 0:
         raise SystemExit("device status word is non-zero (%s)" % name)
     bytes_env = eng.algorithmic_bytes_per_env_step() + (n_agents * eng.V * eng.V * 3 * 3 if obs_f32 else 0)
@@ -239,6 +245,12 @@ def main():
     torch.cuda.set_device(local_rank)
     if world != args.gpus:
         raise SystemExit("--gpus %d but the job has %d ranks (WORLD_SIZE)" % (args.gpus, world))
+    # The communicator comes up HERE, not in the barrier that opens the timed region: RCCL builds it in the group's first
+    # collective, and the rollout call that follows that one costs 185 us instead of 125 (the second: 137; then as without a
+    # group -- tools/rccl_short_call_probe.py).  Set-up of the communication library, not of the steps.
+    for _ in range(3):
+        parallel.barrier(dist, local_rank)
+    torch.cuda.synchronize()
 
     game, amap, n_agents = game_spec(args.game, args.agents)
     E = args.envs                                  # per GPU (weak scaling); global batch = world * E
@@ -273,8 +285,7 @@ def main():
     use_rollout = not args.per_step_calls
     chains = 1
     if use_rollout:                                # env ranges the library steps on streams of its own (envs are independent)
-        chains = args.chains if args.chains > 0 else auto_chains(E, args.pipelined)
-        eng.set_rollout_chains(chains)
+        eng.set_rollout_chains(args.chains)        # (0: the library's own choice; what it was is read back after the timed call)
 
     def run_steps(k0, n):
         if do_gather:
@@ -336,6 +347,8 @@ def main():
     torch.cuda.synchronize()                       #  latency, ~1 ms of RCCL, is not part of any rank's K steps)
     dev_ms = ev0.elapsed_time(ev1)
     path = eng.rollout_path() if use_rollout else None  # how the library dispatched the timed call (a fallback must not go unnoticed)
+    if path:
+        chains = path["chains"]
     if eng.status() != 0:
         raise SystemExit("device status word is non-zero")
     plain = use_rollout and not do_gather and not args.no_extras
@@ -354,7 +367,7 @@ def main():
         if args.steps < 1000:
             fw, _, _ = time_rollout(torch, eng, ring, 1000, 0, step0=args.warmup + args.steps, fused=True)
             fused_long_us = fw * 1e6 / 1000
-        eng.set_rollout_chains(chains)
+        eng.set_rollout_chains(args.chains)
         if eng.status() != 0:
             raise SystemExit("device status word is non-zero")
     if dist is not None:

@@ -305,7 +305,7 @@ static Queue *queue_create(DeviceCtx *c) {
 // Queue `index` (0 .. pool_size() - 1) of the device's pool, created on first use; nullptr if that fails.
 Queue *pool_queue(int device, int index) {
     DeviceCtx *c = device_ctx(device);
-    if (!c || index < 0 || index >= kPoolQueues) return nullptr;
+    if (!c || index < 0 || index >= pool_size()) return nullptr;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if (!c->abort_host) {
@@ -322,7 +322,20 @@ Queue *pool_queue(int device, int index) {
     else if (Q) queue_destroy(Q);                   // (another thread was faster)
     return c->pool[index];
 }
-int pool_size() { return kPoolQueues; }
+// How many queues of its own the library may hold.  A process gets about FOUR hardware queues before the hardware scheduler starts
+// time-slicing them (every dispatch then waits for its queue's turn: a 20-step rollout that follows an RCCL barrier 320 us instead of
+// 130; measured: the HIP runtime's queues in use + the library's = 4 fine, 5 not).  The HIP runtime maps its streams onto at most
+// GPU_MAX_HW_QUEUES queues (default 4, created as streams need them): a process that sets it -- bench.py does, to 2 -- tells us
+// how many are left; unset, a plain torch process uses one or two and the pool takes three.  SSD_AQL_QUEUES (1..3) overrides.
+int pool_size() {
+    static const int n = [] {
+        int v = kPoolQueues;
+        if (const char *h = getenv("GPU_MAX_HW_QUEUES")) { const int hq = atoi(h); if (hq >= 1) v = 4 - hq; }
+        if (const char *o = getenv("SSD_AQL_QUEUES")) v = atoi(o);
+        return v < 1 ? 1 : v > kPoolQueues ? kPoolQueues : v;
+    }();
+    return n;
+}
 std::mutex &enqueue_mutex(int device) { return g_dev[device].enqueue_mu; }
 const uint32_t *abort_flag_dev(int device) { return static_cast<const uint32_t *>(g_dev[device].abort_dev); }
 

@@ -1031,6 +1031,8 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
     static const int forced = [] { const char *v = getenv("SSD_ROLLOUT_CHAINS"); return v ? atoi(v) : 0; }();
     int chains = env->rollout_chains > 0 ? env->rollout_chains : forced > 0 ? forced : (env->E < 2048 ? 1 : (env->E >= 6144 && env->E <= 24576) ? 3 : 2);   // measured: profiles/r01_sweep_envs.txt
     if ((flags & SSD_ROLLOUT_FUSED) && env->rollout_chains <= 0 && forced <= 0) chains = 1;   // one launch already covers the whole rollout
+    // (an automatic choice stays within the library's own dispatch queues: ssd_aql.hip, pool_size())
+    if (env->rollout_chains <= 0 && forced <= 0 && chains > ssd::aql::pool_size()) chains = ssd::aql::pool_size();
     // From here on every exit path must give the device's pipelining slot back: the guard does.
     struct PipeGuard {
         ssd_env *env; bool held = false; hipStream_t s;
