@@ -231,7 +231,8 @@ def main():
             dist.barrier()
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": world, "envs_per_gpu": args.envs,
-                              "shards": [list(s) for s in spans]}), file=real_stdout)
+                              "shards": [list(s) for s in spans],
+                              "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}), file=real_stdout)
             real_stdout.flush()
         if dist is not None:
             dist.destroy_process_group()

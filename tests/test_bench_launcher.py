@@ -24,12 +24,17 @@ def test_gpus_2_starts_two_ranks_with_contiguous_shards():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["ranks"] == 2
     assert res["shards"] == [[0, 4096], [4096, 4096]]  # (start, count) of rank 0, rank 1: train_moa.py:127-128's workers
+    # a rank of a process group holds the HIP runtime to two hardware queues (the library then keeps to two of its own: a
+    # process has about four before the hardware scheduler time-slices them -- DESIGN.md, "Dispatch")
+    assert res["gpu_max_hw_queues"] == "2"
 
 
 def test_single_rank_needs_no_launcher():
     p = _run(["--gpus", "1", "--dry-run", "--envs", "100"])
     assert p.returncode == 0, p.stderr.decode()[-2000:]
-    assert json.loads(p.stdout.decode())["shards"] == [[0, 100]]
+    res = json.loads(p.stdout.decode())
+    assert res["shards"] == [[0, 100]]
+    assert res["gpu_max_hw_queues"] is None            # a plain single process leaves the runtime's default alone
 
 
 def test_rank_count_mismatch_is_an_error_not_a_warning():
