@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=None)
     ap.add_argument("--gather", action="store_true", help="RCCL all-gather of obs/rew (one collective per 32 steps)")
+    ap.add_argument("--no-gather-leg", action="store_true", help="a process group's run: skip the separately reported leg with the gather")
     ap.add_argument("--obs-f32", action="store_true", help="separate mode: the kernel writes float32 observations (4x the obs bytes)")
     ap.add_argument("--per-step-calls", action="store_true", help="one Python call per step instead of ssd_rollout_random")
     ap.add_argument("--pipelined", action="store_true", help="ask ssd_rollout_random for SSD_ROLLOUT_PIPELINED (needs --ring >= 2)")
@@ -261,17 +262,22 @@ def main():
     out = eng.alloc_outputs(float32=args.obs_f32)
     do_gather = bool(args.gather and dist is not None)
     GR = 32                                        # --gather: steps per collective (one RCCL all-gather moves GR steps' outputs)
-    gbuf = None
-    if do_gather:                                  # the batched tensors every rank ends up with: [world, GR, E, ...]
+    G = {}                                         # the gather's buffers, streams and events (made on first use)
+
+    def ensure_gather():                           # the batched tensors every rank ends up with: [world, GR, E, ...]
+        if G:
+            return
         # two rings: while the collective of one is in flight on its own stream, the rollout fills the other
-        grings = [(torch.empty((GR,) + tuple(out[0].shape), dtype=out[0].dtype, device=out[0].device),
-                   torch.empty((GR,) + tuple(out[1].shape), dtype=torch.int32, device=out[1].device),
-                   torch.empty((GR,) + tuple(out[2].shape), dtype=torch.uint8, device=out[2].device)) for _ in range(2)]
-        gbuf = (torch.empty((world,) + tuple(grings[0][0].shape), dtype=grings[0][0].dtype, device=out[0].device),
-                torch.empty((world,) + tuple(grings[0][1].shape), dtype=torch.int32, device=out[1].device))
-        comm_stream = torch.cuda.Stream()
-        ring_ready = [torch.cuda.Event() for _ in range(2)]     # the rollout has filled ring i
-        ring_free = [torch.cuda.Event() for _ in range(2)]      # the collective has read ring i
+        G["rings"] = [(torch.empty((GR,) + tuple(out[0].shape), dtype=out[0].dtype, device=out[0].device),
+                       torch.empty((GR,) + tuple(out[1].shape), dtype=torch.int32, device=out[1].device),
+                       torch.empty((GR,) + tuple(out[2].shape), dtype=torch.uint8, device=out[2].device)) for _ in range(2)]
+        G["buf"] = (torch.empty((world,) + tuple(G["rings"][0][0].shape), dtype=G["rings"][0][0].dtype, device=out[0].device),
+                    torch.empty((world,) + tuple(G["rings"][0][1].shape), dtype=torch.int32, device=out[1].device))
+        G["stream"] = torch.cuda.Stream()
+        G["ready"] = [torch.cuda.Event() for _ in range(2)]     # the rollout has filled ring i
+        G["free"] = [torch.cuda.Event() for _ in range(2)]      # the collective has read ring i
+    if do_gather:
+        ensure_gather()
 
     def one_step(k):
         if k % HORIZON == 0:
@@ -288,11 +294,12 @@ def main():
     if use_rollout:                                # env ranges the library steps on streams of its own (envs are independent)
         eng.set_rollout_chains(args.chains)        # (0: the library's own choice; what it was is read back after the timed call)
 
-    def run_steps(k0, n):
-        if do_gather:
+    def run_steps(k0, n, gather=None):
+        if do_gather if gather is None else gather:
             # GR steps into a ring of GR slots, then ONE RCCL all-gather of the ring (obs) and one of the rewards over xGMI:
             # every rank ends up with all ranks' outputs of those steps
             main = torch.cuda.current_stream()
+            grings, gbuf, comm_stream, ring_ready, ring_free = G["rings"], G["buf"], G["stream"], G["ready"], G["free"]
             for c0 in range(k0, k0 + n, GR):
                 m = min(GR, k0 + n - c0)
                 i = (c0 // GR) % 2
@@ -371,7 +378,27 @@ def main():
         eng.set_rollout_chains(args.chains)
         if eng.status() != 0:
             raise SystemExit("device status word is non-zero")
+    # A process group's run also reports the optional gather (north_star: "RCCL gather of obs/reward over xGMI only when a single
+    # batched tensor is requested"): the same rollout in chunks of GR steps, each chunk's observations and rewards all-gathered
+    # (one collective each, on a stream of their own, overlapped with the next chunk's steps).  Every rank takes part.
+    gather_wall = None
+    GK = 2 * GR
+    if plain and dist is not None and not args.no_gather_leg:
+        ensure_gather()
+        run_steps(0, GK, gather=True)              # (warm-up: buffers touched, the communicator's channels for this size built)
+        torch.cuda.synchronize()
+        parallel.barrier(dist, local_rank)
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        run_steps(GK, GK, gather=True)
+        torch.cuda.synchronize()
+        gather_wall = time.perf_counter() - tg
+        parallel.barrier(dist, local_rank)
     if dist is not None:
+        if gather_wall is not None:
+            tgw = torch.tensor([gather_wall], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tgw, op=dist.ReduceOp.MAX)
+            gather_wall = float(tgw[0])
         tw = torch.tensor([wall, dev_ms, fused_wall or 0.0, enq], dtype=torch.float64, device="cuda")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall, dev_ms, enq = float(tw[0]), float(tw[1]), float(tw[3])
@@ -406,6 +433,11 @@ def main():
                          "note": "achieved = algorithmic bytes per step (all concurrent launches) / time per step; each chain's launches "
                                  "run back to back on its own stream, so time per step = launch-to-launch duration of the step kernel", "host_enqueue_us_per_step": enq * 1e6 / args.steps},
         }
+        if gather_wall is not None:
+            res["with_gather"] = {"label": "NOT the headline: the same rollout with every rank's observations and rewards all-gathered to every rank "
+                                           "(one RCCL all-gather of each per %d steps, overlapped with the next %d steps)" % (GR, GR),
+                                  "steps": GK, "ms_per_step": gather_wall * 1e3 / GK, "value": float(E) * n_agents * GK * world / gather_wall,
+                                  "unit": "agent-env-steps/s", "bytes_received_per_rank_per_step": int((out[0].numel() * out[0].element_size() + out[1].numel() * 4) * world)}
         if long_us is not None:
             res["call_overhead_us"] = wall * 1e6 - args.steps * long_us
             res["long_call_us_per_step"] = long_us
