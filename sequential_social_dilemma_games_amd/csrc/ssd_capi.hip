@@ -877,13 +877,14 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     const bool coherent = env_coh != 0 && !key.f32 && ssd::fast_profile(env->p, env->game) > 0 && per_launch <= 4096;
     key.coherent = coherent ? (alternate ? 2 : 1) : 0;
     // Split rollouts (coherent chains with observations, 4 steps or more): the wave that steps an env does not render its
-    // observations -- it leaves a snapshot of the overlay -- and the NEXT step's launch carries a second set of workgroups that
-    // render them while that step is being computed; a last launch of renderer workgroups alone delivers the last step's.  Still
-    // one launch per step and env range (+ 1 per call), every step's observations in its ring slot when the call's work is done;
-    // but the observation phase (1.2 of 5.7 us) is off the chain of dependent launches.  Snapshots alternate between two buffers
-    // (launch k reads the one launch k - 1 wrote and writes the other).  (Two launches per step in one queue -- step, then an
-    // observe launch beside the next step -- do not work: kernels of one queue run one after the other on this device even
-    // without the barrier bit: two chains' launches in ONE queue take 10.6 us per step, in two queues 5.8.)  SSD_AQL_SPLIT=0 turns it off.
+    // observations; the NEXT step's launch carries a second set of workgroups that render them while that step is being computed,
+    // from the very state that launch steps from (the handle's state lives in a pair of buffers: a launch reads one and writes the
+    // other) plus the step's beam marks, which travel as a list; a last launch of renderer workgroups alone delivers the last step's.
+    // Still one launch per step and env range (+ 1 per call and per reset inside it), every step's observations in its ring slot
+    // when the call's work is done; but the observation phase (1.2 of 5.7 us) is off the chain of dependent launches.  (Two
+    // launches per step in one queue -- step, then an observe launch beside the next step -- do not work: kernels of one queue run
+    // one after the other on this device even without the barrier bit: two chains' launches in ONE queue take 10.6 us per step, in
+    // two queues 5.8.)  SSD_AQL_SPLIT=0 turns it off.
     static const int env_split = [] { const char *v = getenv("SSD_AQL_SPLIT"); return v ? atoi(v) : 1; }();
     key.split = (coherent && env_split != 0 && j0.obs != nullptr && per_launch <= 2304) ? 1 : 0;   // (the argument set holds both forms' launches)
     const bool split = key.split && j0.n_steps >= 4;
@@ -931,8 +932,7 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     static const int env_rel = [] { const char *v = getenv("SSD_AQL_REL"); return v ? atoi(v) : -1; }();
     // Coherent chains: only the first packet of the call acquires (what the caller's stream did before -- a set_state, another
     // kernel -- may sit in caches); between the chain's own launches nothing is read through a cache that could be stale
-    // (-0.14 us per step).  The observe launches of a split rollout do acquire: they only READ their snapshot, so an L2 may
-    // still hold the lines as they were two steps ago.
+    // (-0.14 us per step); the renderer workgroups of a split rollout read state and beam lists with agent-scope loads as well.
     const int kAcq = env_acq >= 0 ? env_acq : (coherent ? 0 : 1), kRel = env_rel >= 0 ? env_rel : (coherent ? 0 : 1);
     const int32_t ring = j0.ring, reset_every = j0.reset_every, step0 = j0.step0;
     constexpr int kKinds = AqlState::kKinds;
