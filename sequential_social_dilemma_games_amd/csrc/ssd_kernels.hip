@@ -979,6 +979,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                         const bool covered = inray & (kk < len);
                         bool landed = false;                                            // marks and cleaning already applied
                         bool top_clean = clean;                                         // kind of the mark that survives on this lane's cell
+                        // (upper bound of what skipping this block could give -- no claims at all, wrong results: Cleanup 25 x 18
+                        // 5.68 -> 5.53 us per 4096-env step, 48 x 36 with 10 agents 7.98 -> 7.62 per 2048-env step)
                         if (GAME == 1 && (all_shooters & (all_shooters - 1))) {         // two or more shooters
                             // Which slots cover each cell: one LDS atomic OR per covered lane into the cell's byte of the (still
                             // empty) beam layer.  Sharing a cell matters in two ways.  (1) Beams of different kind: the mark of
