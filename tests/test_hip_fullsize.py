@@ -296,6 +296,43 @@ def test_the_bench_configuration_takes_the_native_dispatch_path():
     assert eng.status() == 0
 
 
+@pytest.mark.parametrize("hwq,chains", [(None, 3), ("2", 2), ("3", 1)])
+def test_automatic_chains_stay_within_the_queue_budget(hwq, chains):
+    """A process has about four hardware queues before the device time-slices them; the HIP runtime takes up to GPU_MAX_HW_QUEUES of
+    them.  The library's pool of dispatch queues is what is left when the process sets that variable (3 otherwise), and an
+    automatic chain count never exceeds the pool: 8192 envs are stepped as 3 chains, as 2 next to a runtime held to 2 queues (what
+    bench.py does as a rank of a process group), as 1 next to one held to 3 -- always through the library's own queues, and with the
+    oracle's results.  (A process of its own each: both libraries read the variable once.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import golden_util as G\n"
+        "from oracle import pyoracle\n"
+        "from sequential_social_dilemma_games_amd import constants as K\n"
+        "from sequential_social_dilemma_games_amd.engine import VecEngine\n"
+        "E = 8192\n"
+        "eng = VecEngine(K.GAME_HARVEST, None, num_envs=E, num_agents=5, seed=11)\n"
+        "ora = pyoracle.Oracle(K.GAME_HARVEST, K.HARVEST_MAP, E, 5, G.default_lut(), seed=11)\n"
+        "out = eng.alloc_outputs(); ring = tuple(t.unsqueeze(0) for t in out)\n"
+        "eng.rollout_random(12, *ring, reset_every=1000, step0=0); torch.cuda.synchronize()\n"
+        "ora.reset()\n"
+        "for k in range(12): _, o_obs, o_rew, _ = ora.step_random(want_obs=(k == 11))\n"
+        "assert np.array_equal(ring[1][0].cpu().numpy(), o_rew) and np.array_equal(ring[0][0].cpu().numpy(), o_obs)\n"
+        "p = eng.rollout_path(); assert eng.status() == 0\n"
+        "print('PATH', p['aql'], p['chains'])\n") % (root, os.path.join(root, "tests"))
+    env = dict(os.environ)
+    for k in ("GPU_MAX_HW_QUEUES", "SSD_AQL_QUEUES", "SSD_ROLLOUT_CHAINS", "SSD_AQL"):
+        env.pop(k, None)
+    if hwq:
+        env["GPU_MAX_HW_QUEUES"] = hwq
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and ("PATH True %d" % chains) in out, out[-1500:]
+
+
 @pytest.mark.parametrize("mode", ["calls", "chains", "chains3", "fused", "pipelined"])
 @pytest.mark.parametrize("cfg", ["harvest25x38", "cleanup48x36"])
 def test_enlarged_maps_at_their_bench_sizes(cfg, mode):
