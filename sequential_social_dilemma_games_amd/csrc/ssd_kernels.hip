@@ -1520,10 +1520,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         }
         if (roll) write_state(0u);
         // (the launch that follows in the chain starts when this one has ended: every store of this wave has landed by then.
-        // Measured alternatives: the state left dirty in L2 and written back by an agent-scope release on the packet instead --
-        // no wait here -- 5.48 against 5.45 us per step; the same without the release, which is only right while every env
-        // stays on its XCD, 5.14: the 0.3 us this wait and the write-through cost are the price of a hand-off that is right
-        // wherever the next launch's wave runs)
+        // Measured alternative: the state left dirty in L2 and written back by an agent-scope release on the packet instead --
+        // no wait here -- 5.48 against 5.45 us per step.  Without that release the results are wrong even while every env
+        // stays on its XCD: an sc1 load does not return what an earlier launch left dirty in the same L2.)
 #ifndef SSD_EXP_NO_END_WAIT
         if constexpr (PIPE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
