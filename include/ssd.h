@@ -155,7 +155,9 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
 enum { SSD_PATH_AQL = 1, SSD_PATH_COHERENT = 2, SSD_PATH_SPLIT = 4, SSD_PATH_FUSED = 8, SSD_PATH_PIPELINED = 16 };
 int ssd_rollout_path(const ssd_env *env);
 
-/* Number of chains ssd_rollout_random uses: 1..8, or 0 = automatic (1 below 2048 envs, 3 from 6144 to 24576, else 2). */
+/* Number of chains ssd_rollout_random uses: 1..8, or 0 = automatic (1 below 2048 envs, 3 from 6144 to 24576, else 2 -- and never
+ * more than the library has dispatch queues of its own: 3 per device, or 4 - GPU_MAX_HW_QUEUES when the process sets that
+ * variable for the HIP runtime: a process has about four hardware queues before the device time-slices them). */
 int ssd_set_rollout_chains(ssd_env *env, int32_t chains);
 
 /* Observation of the current state without stepping (the per-agent part of map_env.py:189-199). */
