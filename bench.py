@@ -243,8 +243,14 @@ def main():
     from sequential_social_dilemma_games_amd.engine import VecEngine
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    dist, rank, world, local_rank = parallel.init_process_group("nccl")
+    # SSD_BENCH_REHEARSAL=1: the N ranks share the GPUs there are (rank r on device r % count) and talk over gloo -- the multi-rank
+    # control flow of this file on a box with fewer GPUs than ranks (tests/test_multiprocess_gpu.py); its line says so.
+    rehearsal = os.environ.get("SSD_BENCH_REHEARSAL") == "1"
+    dist, rank, world, local_rank = parallel.init_process_group("gloo" if rehearsal else "nccl")
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    red_dev = "cpu" if rehearsal else "cuda"        # where the timing reductions live (gloo: host tensors)
     if world != args.gpus:
         raise SystemExit("--gpus %d but the job has %d ranks (WORLD_SIZE)" % (args.gpus, world))
     # The communicator comes up HERE, not in the barrier that opens the timed region: RCCL builds it in the group's first
@@ -260,7 +266,7 @@ def main():
                                                      local_rank=local_rank, seed=0)
     assert (start, count) == (rank * E, E)
     out = eng.alloc_outputs(float32=args.obs_f32)
-    do_gather = bool(args.gather and dist is not None)
+    do_gather = bool(args.gather and dist is not None and not rehearsal)
     GR = 32                                        # --gather: steps per collective (one RCCL all-gather moves GR steps' outputs)
     G = {}                                         # the gather's buffers, streams and events (made on first use)
 
@@ -383,7 +389,7 @@ def main():
     # (one collective each, on a stream of their own, overlapped with the next chunk's steps).  Every rank takes part.
     gather_wall = None
     GK = 2 * GR
-    if plain and dist is not None and not args.no_gather_leg:
+    if plain and dist is not None and not args.no_gather_leg and not rehearsal:
         ensure_gather()
         run_steps(0, GK, gather=True)              # (warm-up: buffers touched, the communicator's channels for this size built)
         torch.cuda.synchronize()
@@ -396,10 +402,10 @@ def main():
         parallel.barrier(dist, local_rank)
     if dist is not None:
         if gather_wall is not None:
-            tgw = torch.tensor([gather_wall], dtype=torch.float64, device="cuda")
+            tgw = torch.tensor([gather_wall], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tgw, op=dist.ReduceOp.MAX)
             gather_wall = float(tgw[0])
-        tw = torch.tensor([wall, dev_ms, fused_wall or 0.0, enq], dtype=torch.float64, device="cuda")
+        tw = torch.tensor([wall, dev_ms, fused_wall or 0.0, enq], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall, dev_ms, enq = float(tw[0]), float(tw[1]), float(tw[3])
         fused_wall = float(tw[2]) if fused_wall is not None else None
@@ -415,7 +421,7 @@ def main():
         res = {
             "metric": "agent-env-steps/sec (random actions)", "value": value, "unit": "agent-env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_us * 1e-3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.obs_f32 else "u8", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.obs_f32 else "u8", "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL: %d ranks on %d GPU(s), gloo -- not a scaling figure" % (world, torch.cuda.device_count()),
             "config": {"workload": "%s %dx%d, %d agents, %d envs per GPU, uniform random actions, reset every %d steps"
                                    % (args.game, eng.H, eng.W, n_agents, E, HORIZON),
                        "envs_per_gpu": E, "agents": n_agents, "obs": ("float32" if args.obs_f32 else "uint8") + " [E,N,15,15,3]", "launches_per_step": chains, "enqueue": ("ssd_rollout_random, %d chain(s) of %d envs" % (chains, E // chains)) if use_rollout else "one call per step",

@@ -97,6 +97,30 @@ def test_two_ranks_on_one_gpu_equal_one_engine(game, tmp_path):
         assert p.returncode == 0 and ("rank %d ok" % rank) in o, "rank %d:\n%s" % (rank, o[-3000:])
 
 
+def test_bench_with_two_ranks_rehearsed_on_one_gpu():
+    """bench.py's multi-rank control flow (ranks, shards with env_index_base, barriers, the max-over-ranks reduction, rank 0's one
+    JSON line) as torch.distributed.run starts it -- on this one GPU: SSD_BENCH_REHEARSAL=1 puts both ranks on the device there
+    is and uses gloo.  Not a scaling measurement; the line says so."""
+    import json
+    port = _free_port()
+    env = dict(os.environ, SSD_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--no-configs", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["rccl_ranks"] == 2 and "REHEARSAL" in res["data"]
+    assert res["config"]["parallelism"] == "env-shard x2" and res["config"]["envs_per_gpu"] == 4096
+    # both ranks' 20 steps of 4096 envs x 5 agents over the slower rank's time
+    assert abs(res["value"] - 2 * 4096 * 5 * 20 / (res["ms_per_step"] * 1e-3 * 20)) < 1e-6 * res["value"]
+    assert res["config"]["dispatch"].startswith("AQL packets")
+    assert res["fused_rollout"]["value"] > 0 and res["call_overhead_us"] > 0
+
+
 _LOAD_SCRIPT = r'''
 import sys, time
 sys.path.insert(0, %(root)r)
