@@ -358,7 +358,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     //      step's beam marks (p.beam_list_in); or, for the rare step that left one, the overlay snapshot (p.snap_in) ----
     if constexpr (MODE == kModeStep && PIPE == 2 && STD && NA > 0 && NA % 5 == 0 && !F32 && FAST != 0) {
         // (measured: the renderer workgroups FIRST in the grid: 6.44 against 5.33 us per step; renderer waves that start their work
-        // out of phase, by up to 0.3 / 0.7 us: 5.56 / 5.53 against 5.35 -- neither role of a launch has slack)
+        // out of phase, by up to 0.3 / 0.7 us: 5.56 / 5.53 against 5.35 -- neither role of a launch has slack; the renderer waves
+        // of an env in the env's own workgroup, behind its env waves: 5.65 against 5.30, with 2 envs per workgroup 5.40 against 5.33)
         if ((p.snap_mode & 2) && blk >= p.blocks_a) {
             const int eb = a_e_begin + (blk - p.blocks_a) * a_epb + wv;
 #ifdef SSD_STAMPS   // renderer waves stamp into the second half of the buffer: [E_total + env][16]
