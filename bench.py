@@ -12,16 +12,24 @@ HBM when the timed region starts; `horizon` auto-resets are inside the timed reg
 N > 1: one rank per GPU under torch.distributed.run (RCCL).  When the process is not already a rank of such a
 job (WORLD_SIZE unset) it starts the N ranks itself -- as a CHILD process, before this process has touched
 torch or the GPU -- and relays rank 0's JSON line.  Envs are sharded by global index with no data-path
-collective (weak scaling: --envs is per GPU).  `--gather` adds the optional RCCL all-gather of obs / rew
-over xGMI.  `--dry-run` is the launcher and sharding alone (gloo, no GPU, no engine): what the CPU test runs.
+collective (weak scaling: --envs is per GPU).  `--dry-run` is the launcher and sharding alone (gloo, no GPU, no
+engine): what the CPU tests run.
 
-Prints ONE JSON line (rank 0).  ONE clock: `value`, `ms_per_step` and `roofline.frac` all come from the wall
-time of the K timed steps (barrier + synchronize on both sides, max over ranks); the HIP-event duration of
-the same region on the launch stream is reported next to it (`roofline.hip_event_us_per_step`).
-`roofline.achieved` = algorithmic bytes per step (bytes / env-step x envs) / time per step.
-`cpu_baseline` = the C oracle (a port of the reference algorithm, oracle/ssd_oracle.c) timed on this host,
-one core, bounded sample.  `configs` = the other single-GPU configurations of BASELINE.json, a few hundred
-steps each (N = 1 only).
+Prints ONE JSON line (rank 0).  THE HEADLINE COMES FIRST AND CANNOT BE LOST: `value`, `ms_per_step`, `roofline` are
+computed as soon as the K timed steps are done; everything after that -- the call-overhead leg, the fused leg, the
+policy-step legs, the other configurations, the CPU baseline, the optional gather legs -- is an OPTIONAL LEG that
+runs inside its own guard: whatever it raises (an exception, SystemExit, an out-of-memory error) lands as
+{"error": "..."} in that leg's slot of the line, and the line is printed with exit status 0 all the same.  Legs that
+contain collectives (the gather legs) are opt-in (`--gather-leg`): a rank that fails inside one cannot be waited for.
+
+ONE clock: `value`, `ms_per_step` and `roofline.frac` all come from the wall time of the K timed steps (barrier +
+synchronize on both sides, max over ranks); the HIP-event duration of the same region on the launch stream is
+reported next to it (`roofline.hip_event_us_per_step`).  `roofline.achieved` = algorithmic bytes per step
+(bytes / env-step x envs) / time per step.  `cpu_baseline` = the C oracle (a port of the reference
+algorithm, oracle/ssd_oracle.c) timed on this host, one core, bounded sample.  `configs` = the other single-GPU
+configurations of BASELINE.json, a few hundred steps each (N = 1 only).  `policy_step` = the step with
+CALLER-SUPPLIED actions (what the reference's callers do: env.step(policy actions)): per-call stepping through the
+batched adapter, and ssd_rollout_actions chunks.
 """
 import argparse
 import json
@@ -34,7 +42,7 @@ import time
 # queues (default 4), the library adds queues of its own, and beyond FOUR queues per process the hardware scheduler time-slices
 # them: a rollout call that follows an RCCL barrier then takes 320 us instead of 130 (measured under torch.distributed.run: 3 or
 # more here -> 16.2 us per step of a 20-step call, 1 or 2 -> 6.7).  With 2 for the runtime the library keeps to 2 of its own
-# (ssd_aql.hip, pool_size()).  Read by the runtime when it loads: set before torch is imported; an explicit setting wins.
+# (include/ssd.h, "the queue rule").  Read by the runtime when it loads: set before torch is imported; an explicit setting wins.
 if "MASTER_PORT" in os.environ or int(os.environ.get("WORLD_SIZE", "1")) > 1:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
@@ -43,8 +51,9 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s achievable
+XGMI_LINK_GBS = 153.0        # per direct peer link (7 per GPU)
 HORIZON = 1000               # run_scripts/train_baseline.py:131
-ROUND = "r02"
+ROUND = "r03"
 
 
 def _oracle_worker(game, amap, n_agents, E, seconds, seed, out, idx):
@@ -62,11 +71,10 @@ def _oracle_worker(game, amap, n_agents, E, seconds, seed, out, idx):
     out[idx] = (steps, time.perf_counter() - t0)
 
 
-def cpu_baseline(game, amap, n_agents, target_s=6.0):
+def cpu_baseline(game, amap, n_agents, target_s=6.0, E=512):
     """The oracle on the host cores over a bounded sample of the same workload: one core (the headline `value` of this
     object), then every core the process may use (independent env shards, one thread each; the C call releases the GIL)."""
     import threading
-    E = 512
     out = [None]
     _oracle_worker(game, amap, n_agents, E, target_s, 0, out, 0)
     steps, dt = out[0]
@@ -113,13 +121,16 @@ def spawn_ranks(n, argv):
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
     lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.lstrip().startswith("{")]
     rc = proc.returncode
-    if rc == 0 and not lines:
-        print("bench.py: the %d-rank job printed no JSON line" % n, file=sys.stderr)
-        rc = 1
-    if lines:
-        print(lines[-1])
-        sys.stdout.flush()
-    return rc
+    if not lines:
+        print("bench.py: the %d-rank job printed no JSON line (exit status %d)" % (n, rc), file=sys.stderr)
+        return rc or 1
+    print(lines[-1])
+    sys.stdout.flush()
+    if rc:
+        # the headline is out; a non-zero status of the job after that (a rank that died in an optional leg, a slow teardown)
+        # must not make the caller throw the line away
+        print("bench.py: the %d-rank job ended with status %d AFTER rank 0 had printed its line" % (n, rc), file=sys.stderr)
+    return 0
 
 
 GAMES = {"harvest": (0, "HARVEST_MAP", 5), "cleanup": (1, "CLEANUP_MAP", 5),
@@ -135,10 +146,31 @@ def game_spec(name, agents=None):
     return game, amap, (n if agents is None else agents)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# optional legs: each in its own guard
+# ---------------------------------------------------------------------------------------------------------------
+def run_leg(res, key, fn):
+    """One optional leg.  Its result goes to res[key]; whatever it raises goes there as {"error": ...} instead -- the headline
+    that is already in `res` is never in danger.  SSD_BENCH_FAIL_LEG=<key>[,<key>...] makes the named legs fail (tests)."""
+    try:
+        if key in os.environ.get("SSD_BENCH_FAIL_LEG", "").split(","):
+            raise RuntimeError("injected failure (SSD_BENCH_FAIL_LEG)")
+        out = fn()
+        if out is not None:
+            res[key] = out
+        return True
+    except KeyboardInterrupt:
+        raise
+    except BaseException as exc:                   # SystemExit and MemoryError included
+        res[key] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:400])}
+        print("bench.py: optional leg %r failed: %s: %s" % (key, type(exc).__name__, exc), file=sys.stderr)
+        return False
 
 
-def time_rollout(torch, eng, ring, steps, warmup, step0=0, **kw):
-    """W untimed + K timed steps of eng.rollout_random (calls of at most 1000 steps).  Returns (wall s, HIP-event ms, enqueue s)."""
+def time_rollout(torch, eng, ring, steps, warmup, step0=0, busy=None, **kw):
+    """W untimed + K timed steps of eng.rollout_random (calls of at most 1000 steps).  Returns (wall s, HIP-event ms, enqueue s).
+    busy: a callable that puts a (short) kernel on the stream right before the timed calls -- the call then forks from a stream
+    with work pending, as a rollout inside a training loop does."""
     def run(k0, n):
         for c0 in range(k0, k0 + n, 1000):
             eng.rollout_random(min(1000, k0 + n - c0), ring[0], ring[1], ring[2], reset_every=HORIZON, step0=c0, **kw)
@@ -151,6 +183,8 @@ def time_rollout(torch, eng, ring, steps, warmup, step0=0, **kw):
     ev0.record()                                   # (before the opening synchronize: see main())
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if busy is not None:
+        busy()
     run(step0 + warmup, steps)
     ev1.record()
     enq = time.perf_counter() - t0
@@ -159,28 +193,93 @@ def time_rollout(torch, eng, ring, steps, warmup, step0=0, **kw):
     return wall, ev0.elapsed_time(ev1), enq
 
 
-def config_leg(torch, name, E, steps=400, warmup=50, obs_f32=False, pipelined=False, ring_slots=1):
+def config_leg(torch, name, E, steps=400, warmup=50, obs_f32=False):
     """One of the other single-GPU workloads, stepped the way the headline is (ssd_rollout_random, automatic chains)."""
     from sequential_social_dilemma_games_amd.engine import VecEngine
     game, amap, n_agents = game_spec(name)
     eng = VecEngine(game, amap, num_envs=E, num_agents=n_agents, seed=0)
-    out = eng.alloc_outputs(float32=obs_f32)
-    ring = tuple(t.unsqueeze(0) for t in out) if ring_slots <= 1 else \
-        tuple(torch.empty((ring_slots,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in out)
-    eng.set_rollout_chains(0)                      # the library's own choice
-    wall, dev_ms, _ = time_rollout(torch, eng, ring, steps, warmup, pipelined=pipelined)
-    chains = eng.rollout_path()["chains"]
-    if eng.status() != 0:
-        raise SystemExit("device status word is non-zero (%s)" % name)
-    bytes_env = eng.algorithmic_bytes_per_env_step() + (n_agents * eng.V * eng.V * 3 * 3 if obs_f32 else 0)
-    us = wall * 1e6 / steps
-    res = {"workload": "%s %dx%d, %d agents, %d envs%s%s" % (name, eng.H, eng.W, n_agents, E, ", float32 obs" if obs_f32 else "",
-                                                            ", pipelined launches (ring %d)" % ring_slots if pipelined else ""),
-           "steps": steps, "warmup": warmup, "ms_per_step": us * 1e-3, "value": E * n_agents * steps / wall,
-           "bytes_per_env_step": bytes_env, "frac": bytes_env * E / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-           "hip_event_us_per_step": dev_ms * 1e3 / steps, "chains": chains}
-    eng.close()
-    return res
+    try:
+        out = eng.alloc_outputs(float32=obs_f32)
+        ring = tuple(t.unsqueeze(0) for t in out)
+        eng.set_rollout_chains(0)                  # the library's own choice
+        wall, dev_ms, _ = time_rollout(torch, eng, ring, steps, warmup)
+        path = eng.rollout_path()
+        if eng.status() != 0:
+            raise RuntimeError("device status word is non-zero (%s)" % name)
+        bytes_env = eng.algorithmic_bytes_per_env_step() + (n_agents * eng.V * eng.V * 3 * 3 if obs_f32 else 0)
+        us = wall * 1e6 / steps
+        return {"workload": "%s %dx%d, %d agents, %d envs%s" % (name, eng.H, eng.W, n_agents, E, ", float32 obs" if obs_f32 else ""),
+                "steps": steps, "warmup": warmup, "ms_per_step": us * 1e-3, "value": E * n_agents * steps / wall,
+                "bytes_per_env_step": bytes_env, "frac": bytes_env * E / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "hip_event_us_per_step": dev_ms * 1e3 / steps, "chains": path["chains"], "split": path["split"]}
+    finally:
+        eng.close()
+
+
+def policy_step_leg(torch, game, amap, n_agents, E, steps=300, K=20):
+    """The step with CALLER-SUPPLIED actions: what the reference's callers do (visuallizer_rllib.py:121-153; RLlib's sampler behind
+    train_baseline.py:71-81).  (a) SSDVectorEnv.step(device action tensor): one Python call, one hipLaunchKernel of the plain
+    step kernel and, when the horizon comes, one reset launch per step; (b) the same step dispatched through the library's chains
+    (SSD_STEP_CHAINS); (c) ssd_rollout_actions: chunks of K steps per call (synchronised after every call, as the driver's
+    K-step region is) and one long call.  us per 4096-env step each; actions are a fixed random tensor on the device."""
+    from sequential_social_dilemma_games_amd.vector_env import SSDVectorEnv
+    na = 8 if game == 0 else 9
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1)
+    venv = SSDVectorEnv(game, E, n_agents, horizon=HORIZON, ascii_map=amap, seed=0)
+    eng = venv.engine
+    try:
+        acts = torch.randint(0, na, (K, E, n_agents), dtype=torch.int32, device="cuda", generator=gen)
+        venv.reset()
+        out = {"label": "NOT the headline: steps with caller-supplied actions (a fixed random int32 tensor on the device), %d envs" % E,
+               "unit": "us per step", "steps": steps}
+
+        def per_call(fn, n):
+            for i in range(20):
+                fn(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e6 / n
+        out["vector_env_step_us"] = per_call(lambda i: venv.step(acts[i % K]), steps)
+        out["engine_step_us"] = per_call(lambda i: eng.step(acts[i % K], out=venv._out), steps)
+        out["engine_step_via_chains_us"] = per_call(lambda i: eng.step(acts[i % K], out=venv._out, chains=True), steps)
+        out["engine_step_via_chains_dispatch"] = eng.rollout_path()
+        ring = tuple(t.unsqueeze(0) for t in venv._out)
+        eng.set_rollout_chains(0)
+        calls = max(3, steps // K)
+
+        def chunk(i):
+            eng.rollout_actions(acts, K, ring[0], ring[1], ring[2], reset_every=HORIZON, step0=(i * K) % HORIZON)
+            torch.cuda.synchronize()
+        for i in range(3):
+            chunk(i)
+        t0 = time.perf_counter()
+        for i in range(calls):
+            chunk(i)
+        out["rollout_actions_k%d_us_per_step" % K] = (time.perf_counter() - t0) * 1e6 / (calls * K)
+        out["rollout_actions_dispatch"] = eng.rollout_path()
+        t0 = time.perf_counter()
+        eng.rollout_actions(acts, 1000, ring[0], ring[1], ring[2], reset_every=HORIZON, step0=0)
+        torch.cuda.synchronize()
+        out["rollout_actions_long_call_us_per_step"] = (time.perf_counter() - t0) * 1e6 / 1000
+
+        def fchunk(i):
+            eng.rollout_actions(acts, K, ring[0], ring[1], ring[2], reset_every=HORIZON, step0=(i * K) % HORIZON, fused=True)
+            torch.cuda.synchronize()
+        for i in range(3):
+            fchunk(i)
+        t0 = time.perf_counter()
+        for i in range(calls):
+            fchunk(i)
+        out["rollout_actions_fused_k%d_us_per_step" % K] = (time.perf_counter() - t0) * 1e6 / (calls * K)
+        if eng.status() != 0:
+            raise RuntimeError("device status word is non-zero")
+        return out
+    finally:
+        eng.close()
 
 
 def main():
@@ -191,17 +290,22 @@ def main():
     ap.add_argument("--game", default="harvest", choices=sorted(GAMES))
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=None)
-    ap.add_argument("--gather", action="store_true", help="RCCL all-gather of obs/rew (one collective per 32 steps)")
-    ap.add_argument("--no-gather-leg", action="store_true", help="a process group's run: skip the separately reported leg with the gather")
+    ap.add_argument("--gather", action="store_true", help="the WHOLE run with an RCCL all-gather of obs/rew (one collective per --gather-steps steps)")
+    ap.add_argument("--gather-leg", action="store_true", help="a process group's run: also report, separately, the rollout with the "
+                    "observations and rewards (a) all-gathered to every rank, (b) gathered to rank 0 (opt-in: legs with collectives)")
+    ap.add_argument("--gather-steps", type=int, default=32, help="steps per collective of the gather modes")
     ap.add_argument("--obs-f32", action="store_true", help="separate mode: the kernel writes float32 observations (4x the obs bytes)")
     ap.add_argument("--per-step-calls", action="store_true", help="one Python call per step instead of ssd_rollout_random")
-    ap.add_argument("--pipelined", action="store_true", help="ask ssd_rollout_random for SSD_ROLLOUT_PIPELINED (needs --ring >= 2)")
     ap.add_argument("--ring", type=int, default=1, help="output ring slots of ssd_rollout_random (step k writes slot k %% ring)")
     ap.add_argument("--chains", type=int, default=0, help="env ranges stepped concurrently by ssd_rollout_random (0 = automatic)")
+    ap.add_argument("--strict-dispatch", action="store_true", help="refuse to time anything if a rank's rollout did not take the "
+                    "library's own dispatch queues (default: time it, and say so loudly in the line and on stderr)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` legs (the other single-GPU workloads)")
-    ap.add_argument("--no-extras", action="store_true", help="only the headline: no fused leg, call-overhead leg, configs, cpu baseline")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline: no optional leg at all")
     ap.add_argument("--dry-run", action="store_true", help="launcher + sharding only: gloo ranks, no GPU, no engine")
+    ap.add_argument("--dry-run-legs", action="store_true", help="--dry-run: also run the legs that need no GPU (a short cpu_baseline) "
+                    "through the same guards as the real run")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -219,6 +323,10 @@ def main():
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    def emit(res):
+        print(json.dumps(res), file=real_stdout)
+        real_stdout.flush()
+
     from sequential_social_dilemma_games_amd import parallel
     if args.dry_run:
         dist, rank, world, local_rank = parallel.init_process_group("gloo")
@@ -231,16 +339,19 @@ def main():
             dist.all_gather_object(spans, span)
             dist.barrier()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": world, "envs_per_gpu": args.envs,
-                              "shards": [list(s) for s in spans],
-                              "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}), file=real_stdout)
-            real_stdout.flush()
+            res = {"dry_run": True, "n_gpus": world, "ranks": world, "envs_per_gpu": args.envs,
+                   "shards": [list(s) for s in spans], "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
+            if args.dry_run_legs:                  # (the guards of the real run, on the legs that need no GPU)
+                game, amap, n_agents = game_spec(args.game, args.agents)
+                run_leg(res, "cpu_baseline", lambda: cpu_baseline(game, amap, n_agents, target_s=0.3, E=32))
+                run_leg(res, "configs", lambda: [{"workload": "(dry run: no GPU)"}])
+            emit(res)
         if dist is not None:
             dist.destroy_process_group()
         return
 
     import torch
-    from sequential_social_dilemma_games_amd.engine import VecEngine
+    from sequential_social_dilemma_games_amd.engine import VecEngine  # noqa: F401
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     # SSD_BENCH_REHEARSAL=1: the N ranks share the GPUs there are (rank r on device r % count) and talk over gloo -- the multi-rank
@@ -267,21 +378,22 @@ def main():
     assert (start, count) == (rank * E, E)
     out = eng.alloc_outputs(float32=args.obs_f32)
     do_gather = bool(args.gather and dist is not None and not rehearsal)
-    GR = 32                                        # --gather: steps per collective (one RCCL all-gather moves GR steps' outputs)
+    GR = max(1, args.gather_steps)                 # gather modes: steps per collective (one RCCL collective moves GR steps' outputs)
     G = {}                                         # the gather's buffers, streams and events (made on first use)
 
-    def ensure_gather():                           # the batched tensors every rank ends up with: [world, GR, E, ...]
-        if G:
-            return
-        # two rings: while the collective of one is in flight on its own stream, the rollout fills the other
-        G["rings"] = [(torch.empty((GR,) + tuple(out[0].shape), dtype=out[0].dtype, device=out[0].device),
-                       torch.empty((GR,) + tuple(out[1].shape), dtype=torch.int32, device=out[1].device),
-                       torch.empty((GR,) + tuple(out[2].shape), dtype=torch.uint8, device=out[2].device)) for _ in range(2)]
-        G["buf"] = (torch.empty((world,) + tuple(G["rings"][0][0].shape), dtype=G["rings"][0][0].dtype, device=out[0].device),
-                    torch.empty((world,) + tuple(G["rings"][0][1].shape), dtype=torch.int32, device=out[1].device))
-        G["stream"] = torch.cuda.Stream()
-        G["ready"] = [torch.cuda.Event() for _ in range(2)]     # the rollout has filled ring i
-        G["free"] = [torch.cuda.Event() for _ in range(2)]      # the collective has read ring i
+    def ensure_gather(root_only=False):            # the batched tensors: [world, GR, E, ...] on every rank (all-gather) / on rank 0
+        if "rings" not in G:
+            # two rings: while the collective of one is in flight on its own stream, the rollout fills the other
+            G["rings"] = [(torch.empty((GR,) + tuple(out[0].shape), dtype=out[0].dtype, device=out[0].device),
+                           torch.empty((GR,) + tuple(out[1].shape), dtype=torch.int32, device=out[1].device),
+                           torch.empty((GR,) + tuple(out[2].shape), dtype=torch.uint8, device=out[2].device)) for _ in range(2)]
+            G["stream"] = torch.cuda.Stream()
+            G["ready"] = [torch.cuda.Event() for _ in range(2)]     # the rollout has filled ring i
+            G["free"] = [torch.cuda.Event() for _ in range(2)]      # the collective has read ring i
+        need = world > 1 and (rank == 0 or not root_only)
+        if need and "buf" not in G:
+            G["buf"] = (torch.empty((world,) + tuple(G["rings"][0][0].shape), dtype=G["rings"][0][0].dtype, device=out[0].device),
+                        torch.empty((world,) + tuple(G["rings"][0][1].shape), dtype=torch.int32, device=out[1].device))
     if do_gather:
         ensure_gather()
 
@@ -297,20 +409,23 @@ def main():
         tuple(torch.empty((args.ring,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in out)
     use_rollout = not args.per_step_calls
     chains = 1
-    if use_rollout:                                # env ranges the library steps on streams of its own (envs are independent)
+    if use_rollout:                                # env ranges the library steps on queues of its own (envs are independent)
         eng.set_rollout_chains(args.chains)        # (0: the library's own choice; what it was is read back after the timed call)
 
     def run_steps(k0, n, gather=None):
-        if do_gather if gather is None else gather:
-            # GR steps into a ring of GR slots, then ONE RCCL all-gather of the ring (obs) and one of the rewards over xGMI:
-            # every rank ends up with all ranks' outputs of those steps
-            main = torch.cuda.current_stream()
-            grings, gbuf, comm_stream, ring_ready, ring_free = G["rings"], G["buf"], G["stream"], G["ready"], G["free"]
+        """gather: None = as the run was asked (--gather), "all" = all-gather to every rank, "root" = gather to rank 0."""
+        mode = ("all" if do_gather else None) if gather is None else gather
+        if mode:
+            # GR steps into a ring of GR slots, then ONE RCCL collective of the ring's observations and one of its rewards over
+            # xGMI, on a stream of their own, while the next GR steps fill the other ring
+            main_s = torch.cuda.current_stream()
+            grings, comm_stream, ring_ready, ring_free = G["rings"], G["stream"], G["ready"], G["free"]
+            gbuf = G.get("buf")
             for c0 in range(k0, k0 + n, GR):
                 m = min(GR, k0 + n - c0)
                 i = (c0 // GR) % 2
                 gring = grings[i]
-                main.wait_event(ring_free[i])          # (no-op until the event has been recorded once)
+                main_s.wait_event(ring_free[i])        # (no-op until the event has been recorded once)
                 if use_rollout:
                     eng.rollout_random(m, gring[0], gring[1], gring[2], reset_every=HORIZON, step0=c0)
                 else:
@@ -318,17 +433,20 @@ def main():
                         if k % HORIZON == 0:
                             eng.reset(obs=gring[0][k % GR])
                         eng.step_random(out=(gring[0][k % GR], gring[1][k % GR], gring[2][k % GR]))
-                ring_ready[i].record(main)
+                ring_ready[i].record(main_s)
                 with torch.cuda.stream(comm_stream):   # the collectives overlap the next chunk's steps
                     comm_stream.wait_event(ring_ready[i])
-                    parallel.all_gather_ring(dist, gring[0], world, out=gbuf[0])
-                    parallel.all_gather_ring(dist, gring[1], world, out=gbuf[1])
+                    if mode == "all":
+                        parallel.all_gather_ring(dist, gring[0], world, out=gbuf[0] if gbuf else None)
+                        parallel.all_gather_ring(dist, gring[1], world, out=gbuf[1] if gbuf else None)
+                    else:
+                        parallel.gather_ring(dist, gring[0], world, rank, out=gbuf[0] if gbuf else None)
+                        parallel.gather_ring(dist, gring[1], world, rank, out=gbuf[1] if gbuf else None)
                     ring_free[i].record(comm_stream)
-            main.wait_stream(comm_stream)              # the K steps are not done before their last collective is
+            main_s.wait_stream(comm_stream)            # the K steps are not done before their last collective is
         elif use_rollout:
             for c0 in range(k0, k0 + n, 1000):
-                eng.rollout_random(min(1000, k0 + n - c0), ring[0], ring[1], ring[2], reset_every=HORIZON, step0=c0,
-                                   pipelined=args.pipelined)
+                eng.rollout_random(min(1000, k0 + n - c0), ring[0], ring[1], ring[2], reset_every=HORIZON, step0=c0)
         else:
             for k in range(k0, k0 + n):
                 one_step(k)
@@ -344,11 +462,27 @@ def main():
     for w0 in range(0, args.warmup, wchunk):
         run_steps(w0, min(wchunk, args.warmup - w0))
     torch.cuda.synchronize()
+    # ---- how did every rank's rollout get dispatched?  Known BEFORE anything is timed, reported per rank.  A rank whose HSA agent
+    #      could not be matched to its HIP device (device = local_rank != 0 has never run before the first multi-GPU job), or whose
+    #      dispatch queues failed their probe, steps through hipLaunchKernel: same results, slower -- never silently. ----
+    my_path = eng.rollout_path() if use_rollout and args.warmup > 0 else None
+    paths = [my_path]
+    if dist is not None:
+        paths = [None] * world
+        dist.all_gather_object(paths, my_path)
+    want_aql = os.environ.get("SSD_AQL", "1") != "0"
+    fallback_ranks = [r for r, p in enumerate(paths) if p is not None and want_aql and not p["aql"]]
+    if fallback_ranks:
+        msg = ("bench.py: rank(s) %s did NOT take the library's own dispatch queues (hipLaunchKernel fallback: SSD_AQL_VERBOSE=1 "
+               "says why); paths: %s" % (fallback_ranks, paths))
+        print("=" * 100 + "\n" + msg + "\n" + "=" * 100, file=sys.stderr)
+        if args.strict_dispatch:
+            raise SystemExit(msg)
     parallel.barrier(dist, local_rank)
     # The opening event is recorded BEFORE the opening synchronize: the timed region then starts on an idle stream, as a rollout
     # call after any synchronize does (an event record just ahead of the call would make the library fork from a "busy" stream:
-    # ~20 us of a 20-step region).  The HIP-event interval therefore also covers that synchronize's return (~10 us): it is the
-    # secondary clock; `value`, `ms_per_step` and `roofline.frac` use the wall clock below.
+    # ~20 us of a 20-step region; that case is the `busy_stream_call` leg below).  The HIP-event interval therefore also covers
+    # that synchronize's return (~10 us): it is the secondary clock; `value`, `ms_per_step` and `roofline.frac` use the wall clock.
     ev0.record()                                   # torch's current stream == the stream the kernels are launched on
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -363,129 +497,183 @@ def main():
     path = eng.rollout_path() if use_rollout else None  # how the library dispatched the timed call (a fallback must not go unnoticed)
     if path:
         chains = path["chains"]
-    if eng.status() != 0:
-        raise SystemExit("device status word is non-zero")
-    plain = use_rollout and not do_gather and not args.no_extras
-    # What one rollout call costs beyond its steps: the same K steps are timed again as part of ONE long call's rate
-    # (1000 steps, same launches); call_overhead_us = wall(K steps) - K x (per-step time of the long call).
-    long_us = None
-    if plain and args.steps < 1000:
-        lw, _, _ = time_rollout(torch, eng, ring, 1000, 0, step0=args.warmup + args.steps, pipelined=args.pipelined)
-        long_us = lw * 1e6 / 1000
-    # Reported separately and labelled: the same K steps as ONE fused kernel launch -- every env
-    # resident in LDS / registers across its steps (SSD_ROLLOUT_FUSED).  Not part of `value`.
-    fused_wall = fused_long_us = None
-    if plain and not args.obs_f32:
-        eng.set_rollout_chains(0)                  # the library's own choice (one launch per GPU: no second stream to fork and join)
-        fused_wall, _, _ = time_rollout(torch, eng, ring, args.steps, args.warmup, fused=True)
-        if args.steps < 1000:
-            fw, _, _ = time_rollout(torch, eng, ring, 1000, 0, step0=args.warmup + args.steps, fused=True)
-            fused_long_us = fw * 1e6 / 1000
-        eng.set_rollout_chains(args.chains)
-        if eng.status() != 0:
-            raise SystemExit("device status word is non-zero")
-    # A process group's run also reports the optional gather (north_star: "RCCL gather of obs/reward over xGMI only when a single
-    # batched tensor is requested"): the same rollout in chunks of GR steps, each chunk's observations and rewards all-gathered
-    # (one collective each, on a stream of their own, overlapped with the next chunk's steps).  Every rank takes part.
-    gather_wall = None
-    GK = 2 * GR
-    if plain and dist is not None and not args.no_gather_leg and not rehearsal:
-        ensure_gather()
-        run_steps(0, GK, gather=True)              # (warm-up: buffers touched, the communicator's channels for this size built)
-        torch.cuda.synchronize()
-        parallel.barrier(dist, local_rank)
-        torch.cuda.synchronize()
-        tg = time.perf_counter()
-        run_steps(GK, GK, gather=True)
-        torch.cuda.synchronize()
-        gather_wall = time.perf_counter() - tg
-        parallel.barrier(dist, local_rank)
+    status = eng.status()
     if dist is not None:
-        if gather_wall is not None:
-            tgw = torch.tensor([gather_wall], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(tgw, op=dist.ReduceOp.MAX)
-            gather_wall = float(tgw[0])
-        tw = torch.tensor([wall, dev_ms, fused_wall or 0.0, enq], dtype=torch.float64, device=red_dev)
+        tw = torch.tensor([wall, dev_ms, enq, float(status)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall, dev_ms, enq = float(tw[0]), float(tw[1]), float(tw[3])
-        fused_wall = float(tw[2]) if fused_wall is not None else None
+        wall, dev_ms, enq, status = float(tw[0]), float(tw[1]), float(tw[2]), int(tw[3])
+    if status != 0:
+        raise SystemExit("device status word is non-zero (%d) on some rank" % status)
 
+    # ---- THE HEADLINE: complete before any optional leg runs ----
+    res = None
+    total_agent_steps = float(E) * n_agents * args.steps * world
+    bytes_env = eng.algorithmic_bytes_per_env_step()
+    if args.obs_f32:                               # the obs term becomes N * 2700 in this mode
+        bytes_env += n_agents * eng.V * eng.V * 3 * 3
     if rank == 0:
-        total_agent_steps = float(E) * n_agents * args.steps * world
         value = total_agent_steps / wall
-        bytes_env = eng.algorithmic_bytes_per_env_step()
-        if args.obs_f32:                           # the obs term becomes N * 2700 in this mode
-            bytes_env += n_agents * eng.V * eng.V * 3 * 3
-        step_us = wall * 1e6 / args.steps           # THE clock: wall time of the K steps, per step
+        step_us = wall * 1e6 / args.steps          # THE clock: wall time of the K steps, per step
         achieved = bytes_env * E / (step_us * 1e-6) / 1e9
+
+        def describe(p):
+            if not p:
+                return "one call per step (hipLaunchKernel)"
+            return "%s, %d chain(s)%s%s%s" % ("AQL packets in the library's own HSA queues" if p["aql"] else "hipLaunchKernel on HIP streams",
+                                               p["chains"], ", coherent kernel variant (no fence between a chain's launches)" if p["coherent"] else "",
+                                               ", observations rendered by the next step's launch" if p["split"] else "",
+                                               ", host-side waits (a profiling tool is attached / SSD_AQL_SYNC)" if p["sync"] else "")
         res = {
             "metric": "agent-env-steps/sec (random actions)", "value": value, "unit": "agent-env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_us * 1e-3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.obs_f32 else "u8", "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL: %d ranks on %d GPU(s), gloo -- not a scaling figure" % (world, torch.cuda.device_count()),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.obs_f32 else "u8",
+            "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL: %d ranks on %d GPU(s), gloo -- not a scaling figure" % (world, torch.cuda.device_count()),
             "config": {"workload": "%s %dx%d, %d agents, %d envs per GPU, uniform random actions, reset every %d steps"
                                    % (args.game, eng.H, eng.W, n_agents, E, HORIZON),
-                       "envs_per_gpu": E, "agents": n_agents, "obs": ("float32" if args.obs_f32 else "uint8") + " [E,N,15,15,3]", "launches_per_step": chains, "enqueue": ("ssd_rollout_random, %d chain(s) of %d envs" % (chains, E // chains)) if use_rollout else "one call per step",
-                       "gather": ("one RCCL all-gather of obs and one of rewards per %d steps, overlapped with the next %d steps" % (GR, GR)) if do_gather else False, "parallelism": "env-shard x%d" % world,
-                       "rccl_ranks": dist.get_world_size() if dist is not None else 1,
-                       "dispatch": ("%s, %d chain(s)%s%s%s" % ("AQL packets in the library's own HSA queues" if path["aql"] else "hipLaunchKernel on HIP streams",
-                                                                path["chains"], ", coherent kernel variant (no fence between a chain's launches)" if path["coherent"] else "",
-                                                                ", observations rendered by the next step's launch" if path["split"] else "",
-                                                                ", pipelined launches" if path["pipelined"] else "")) if path else "one call per step (hipLaunchKernel)"},
+                       "envs_per_gpu": E, "agents": n_agents, "obs": ("float32" if args.obs_f32 else "uint8") + " [E,N,15,15,3]", "launches_per_step": chains,
+                       "enqueue": ("ssd_rollout_random, %d chain(s) of %d envs" % (chains, E // chains)) if use_rollout else "one call per step",
+                       "gather": ("one RCCL all-gather of obs and one of rewards per %d steps, overlapped with the next %d steps" % (GR, GR)) if do_gather else False,
+                       "parallelism": "env-shard x%d" % world, "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+                       "dispatch": describe(path), "dispatch_per_rank": paths, "dispatch_fallback_ranks": fallback_ranks},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "ssd::ssd_env_kernel<%d, 0, %s, ...>" % (game, "true" if args.obs_f32 else "false"), "bytes_per_env_step": bytes_env,
                          "clock": "wall time of the K timed steps (the same clock as value and ms_per_step)",
                          "hip_event_us_per_step": dev_ms * 1e3 / args.steps, "concurrent_launches": chains, "envs_per_launch": E // chains,
                          "note": "achieved = algorithmic bytes per step (all concurrent launches) / time per step; each chain's launches "
-                                 "run back to back on its own stream, so time per step = launch-to-launch duration of the step kernel", "host_enqueue_us_per_step": enq * 1e6 / args.steps},
+                                 "run back to back in its own queue, so time per step = launch-to-launch duration of the step kernel",
+                         "host_enqueue_us_per_step": enq * 1e6 / args.steps},
         }
-        if gather_wall is not None:
-            res["with_gather"] = {"label": "NOT the headline: the same rollout with every rank's observations and rewards all-gathered to every rank "
-                                           "(one RCCL all-gather of each per %d steps, overlapped with the next %d steps)" % (GR, GR),
-                                  "steps": GK, "ms_per_step": gather_wall * 1e3 / GK, "value": float(E) * n_agents * GK * world / gather_wall,
-                                  "unit": "agent-env-steps/s", "bytes_received_per_rank_per_step": int((out[0].numel() * out[0].element_size() + out[1].numel() * 4) * world)}
-        if long_us is not None:
-            res["call_overhead_us"] = wall * 1e6 - args.steps * long_us
-            res["long_call_us_per_step"] = long_us
-        if fused_wall is not None:
-            fus = fused_wall * 1e6 / args.steps
-            res["fused_rollout"] = {
-                "label": "NOT the headline: the same %d steps as ONE kernel launch per GPU (ssd_rollout_random + SSD_ROLLOUT_FUSED), "
-                         "envs resident in LDS across steps; per-step obs / rew / done still written to HBM" % args.steps,
-                "value": total_agent_steps / fused_wall, "unit": "agent-env-steps/s", "us_per_step": fus,
-                "roofline_frac": bytes_env * E / (fus * 1e-6) / 1e9 / HBM_PEAK_GBS}
-            if fused_long_us is not None:
-                res["fused_rollout"]["long_call_us_per_step"] = fused_long_us
         # HBM bytes per step from the PMC counters of the committed profile of this exact workload
-        # (tools/profile_gpu.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE correction)
-        tkey = "%s_%dx%d_n%d_e%d%s" % (args.game.rstrip("0123456789x"), eng.H, eng.W, n_agents, E, "_f32" if args.obs_f32 else "")
-        for rnd in (ROUND, "r01"):
-            tpath = os.path.join(REPO, "profiles", "%s_traffic.json" % rnd)
-            if not os.path.exists(tpath):
-                continue
-            ent = json.load(open(tpath)).get(tkey)
-            if ent and not args.pipelined:
-                res["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
-                res["roofline"]["traffic_source"] = "profiles/%s_traffic.json[%s] (rocprofv3 PMC, same workload; sum over the step's concurrent launches)" % (rnd, tkey)
-                if "rocprof_avg_kernel_us" in ent:
-                    # what rocprofv3 --kernel-trace --stats says one launch of that kernel lasts (committed summary; tracing slows
-                    # the dispatch path down, so this is the kernel's duration in that regime, not the unprofiled step time)
-                    res["roofline"]["rocprof_avg_kernel_us"] = ent["rocprof_avg_kernel_us"]
-                    res["roofline"]["rocprof_source"] = ent.get("rocprof_source")
-                break
-        if world == 1 and not args.no_configs:
-            # BASELINE.json's other single-GPU workloads (SURVEY.md 8d "state both": the 25x38 label; configs[2]; configs[4]'s
-            # per-GPU share), the float32-observation mode and the pipelined launches, a few hundred steps each
+        # (tools/profile_r03.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE correction)
+
+        def traffic():
+            tkey = "%s_%dx%d_n%d_e%d%s" % (args.game.rstrip("0123456789x"), eng.H, eng.W, n_agents, E, "_f32" if args.obs_f32 else "")
+            for rnd in (ROUND, "r02", "r01"):
+                tpath = os.path.join(REPO, "profiles", "%s_traffic.json" % rnd)
+                if not os.path.exists(tpath):
+                    continue
+                ent = json.load(open(tpath)).get(tkey)
+                if ent:
+                    res["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
+                    res["roofline"]["traffic_source"] = "profiles/%s_traffic.json[%s] (rocprofv3 PMC, same workload; sum over the step's concurrent launches)" % (rnd, tkey)
+                    if "rocprof_avg_kernel_us" in ent:
+                        # what rocprofv3 --kernel-trace --stats says one launch of that kernel lasts (committed summary; tracing slows
+                        # the dispatch path down, so this is the kernel's duration in that regime, not the unprofiled step time)
+                        res["roofline"]["rocprof_avg_kernel_us"] = ent["rocprof_avg_kernel_us"]
+                        res["roofline"]["rocprof_source"] = ent.get("rocprof_source")
+                    return
+        run_leg(res, "_traffic", traffic)
+        if "_traffic" in res:                      # (only ever an error slot)
+            res["roofline"]["traffic_error"] = res.pop("_traffic")["error"]
+    holder = res if res is not None else {}        # (every rank runs the legs; only rank 0's slots are printed)
+
+    try:
+        plain = use_rollout and not do_gather and not args.no_extras
+        # ---- optional leg: what one rollout call costs beyond its steps.  The same K steps are timed again as part of ONE long
+        #      call's rate (1000 steps, same launches); call_overhead_us = wall(K steps) - K x (per-step time of the long call) ----
+        if plain and args.steps < 1000:
+            def overhead():
+                lw, _, _ = time_rollout(torch, eng, ring, 1000, 0, step0=args.warmup + args.steps)
+                long_us = lw * 1e6 / 1000
+                holder["long_call_us_per_step"] = long_us
+                return wall * 1e6 - args.steps * long_us
+            run_leg(holder, "call_overhead_us", overhead)
+        # ---- optional leg: the same K steps from a stream that has work pending when the call comes (a rollout inside a training
+        #      loop: policy kernels are still queued), so that the call forks from it -- the headline's region starts on an idle stream
+        if plain:
+            def busy_call():
+                x = torch.zeros(1 << 20, device="cuda")
+                bw, _, _ = time_rollout(torch, eng, ring, args.steps, min(args.warmup, 20), step0=args.warmup + args.steps, busy=lambda: x.add_(1.0))
+                p = eng.rollout_path()
+                return {"label": "NOT the headline: the same %d steps with a (4 MB, ~2 us) kernel pending on the stream when the call comes; "
+                                 "the call then forks from the stream" % args.steps,
+                        "us_per_step": bw * 1e6 / args.steps, "forked": p["forked"]}
+            run_leg(holder, "busy_stream_call", busy_call)
+        # ---- optional leg, reported separately and labelled: the same K steps as ONE fused kernel launch --
+        #      every env resident in LDS / registers across its steps (SSD_ROLLOUT_FUSED).  Not part of `value`. ----
+        if plain and not args.obs_f32:
+            def fused():
+                eng.set_rollout_chains(0)              # the library's own choice (one launch per GPU: no second stream to fork and join)
+                try:
+                    fw, _, _ = time_rollout(torch, eng, ring, args.steps, args.warmup, fused=True)
+                    fus = fw * 1e6 / args.steps
+                    o = {"label": "NOT the headline: the same %d steps as ONE kernel launch per GPU (ssd_rollout_random + SSD_ROLLOUT_FUSED), "
+                                  "envs resident in LDS across steps; per-step obs / rew / done still written to HBM%s"
+                                  % (args.steps, "; this rank's figure" if world > 1 else ""),
+                         "value": float(E) * n_agents * args.steps / fw, "unit": "agent-env-steps/s per GPU", "us_per_step": fus,
+                         "roofline_frac": bytes_env * E / (fus * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                    if args.steps < 1000:
+                        lw, _, _ = time_rollout(torch, eng, ring, 1000, 0, step0=args.warmup + args.steps, fused=True)
+                        o["long_call_us_per_step"] = lw * 1e6 / 1000
+                    if eng.status() != 0:
+                        raise RuntimeError("device status word is non-zero")
+                    return o
+                finally:
+                    eng.set_rollout_chains(args.chains)
+            run_leg(holder, "fused_rollout", fused)
+        # ---- optional legs WITH collectives (opt-in): north_star: "RCCL gather of obs/reward over xGMI only when a single batched
+        #      tensor is requested".  The same rollout in chunks of GR steps, each chunk's observations and rewards (a) all-gathered to
+        #      every rank, (b) gathered to rank 0 (the root ingests its 7 peers' shards over 7 direct links), one
+        #      collective each, on a stream of their own, overlapped with the next chunk's steps.  Every rank takes part. ----
+        if plain and args.gather_leg and dist is not None and not rehearsal:
+            per_rank_bytes = out[0].numel() * out[0].element_size() + out[1].numel() * 4
+            for mode, key in (("all", "with_gather"), ("root", "with_gather_to_root")):
+                def gleg(mode=mode):
+                    GK = 2 * GR
+                    ensure_gather(root_only=(mode == "root"))
+                    run_steps(0, GK, gather=mode)      # (warm-up: buffers touched, the communicator's channels for this size built)
+                    torch.cuda.synchronize()
+                    parallel.barrier(dist, local_rank)
+                    torch.cuda.synchronize()
+                    tg = time.perf_counter()
+                    run_steps(GK, GK, gather=mode)
+                    torch.cuda.synchronize()
+                    gw = time.perf_counter() - tg
+                    parallel.barrier(dist, local_rank)
+                    tgw = torch.tensor([gw], dtype=torch.float64, device=red_dev)
+                    dist.all_reduce(tgw, op=dist.ReduceOp.MAX)
+                    gw = float(tgw[0])
+                    recv = per_rank_bytes * (world - 1)      # what the busiest receiver takes in per step (every rank / the root)
+                    return {"label": "NOT the headline: the same rollout with every rank's observations and rewards %s (one RCCL collective "
+                                     "of each per %d steps, overlapped with the next %d steps)%s"
+                                     % ("all-gathered to every rank" if mode == "all" else "gathered to rank 0", GR, GR,
+                                        "; one rank: the batch is already whole, nothing is copied" if world == 1 else ""),
+                            "steps": GK, "ms_per_step": gw * 1e3 / GK, "value": float(E) * n_agents * GK * world / gw, "unit": "agent-env-steps/s",
+                            "bytes_received_per_rank_per_step": int(recv), "receivers": world if mode == "all" else 1,
+                            "xgmi_per_link_bound_us_per_step": per_rank_bytes / (XGMI_LINK_GBS * 1e9) * 1e6 if world > 1 else 0.0,
+                            "xgmi_note": "every peer has a direct link to the receiver: per link and step one rank's %d bytes, whatever the world size "
+                                         "(all-gather: on all %d x %d links at once; gather: on the root's %d)" % (per_rank_bytes, world, world - 1, world - 1)}
+                run_leg(holder, key, gleg)
+        if rank == 0 and world == 1 and not args.no_extras:
+            # ---- optional leg: the step with caller-supplied actions ----
+            if not args.obs_f32:
+                run_leg(res, "policy_step", lambda: policy_step_leg(torch, game, amap, n_agents, E))
+        if rank == 0 and world == 1 and not args.no_configs:
+            # ---- optional legs: BASELINE.json's other single-GPU workloads (SURVEY.md 8d "state both": the 25x38 label; configs[2];
+            #      configs[4]'s per-GPU share) and the float32-observation mode, a few hundred steps each ----
             eng.close()
-            legs = [("cleanup", 4096, {}), ("harvest25x38", 4096, {}), ("cleanup48x36", 2048, {}),
-                    ("harvest", 4096, {"obs_f32": True}), ("harvest", 2048, {"pipelined": True, "ring_slots": 2})]
-            res["configs"] = [config_leg(torch, name, e, **kw) for name, e, kw in legs]
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(game, amap, n_agents)
-        print(json.dumps(res), file=real_stdout)
-        real_stdout.flush()
+            legs = [("cleanup", 4096, {}), ("harvest25x38", 4096, {}), ("cleanup48x36", 2048, {}), ("harvest", 4096, {"obs_f32": True})]
+            res["configs"] = []
+            for name, e, kw in legs:
+                slot = {}
+                run_leg(slot, "leg", lambda name=name, e=e, kw=kw: config_leg(torch, name, e, **kw))
+                leg = slot.get("leg", {"error": "no result"})
+                if "error" in leg:
+                    leg["workload"] = "%s, %d envs%s" % (name, e, ", float32 obs" if kw.get("obs_f32") else "")
+                res["configs"].append(leg)
+            if os.environ.get("SSD_BENCH_FAIL_LEG", "") and "configs" in os.environ["SSD_BENCH_FAIL_LEG"].split(","):
+                res["configs"] = {"error": "RuntimeError: injected failure (SSD_BENCH_FAIL_LEG)"}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            run_leg(res, "cpu_baseline", lambda: cpu_baseline(game, amap, n_agents))
+    finally:
+        if rank == 0:
+            emit(res)                              # whatever happened after the headline: the line goes out
     if dist is not None:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception as exc:                   # (the line is out: a teardown problem is not a failed run)
+            print("bench.py: destroy_process_group: %s" % exc, file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SSD_ABI_VERSION 1
+#define SSD_ABI_VERSION 2   /* 2: ssd_rollout_actions, SSD_STEP_CHAINS, ssd_profiler_attached; SSD_ROLLOUT_PIPELINED removed */
 
 enum {
     SSD_OK = 0,
@@ -60,20 +60,14 @@ enum {
                                 are 1) starts its next episode in the same launch: MapEnv.reset (map_env.py:214-249) is applied to it
                                 and its observation rows are the reset's (unrotated, :239-240), as if ssd_reset had been called with
                                 the done flags as the mask.  uint8 obs only. */
-    SSD_ROLLOUT_PIPELINED = 1u << 5, /* ssd_rollout_random only, a request: the step launches of a chain alternate between two streams
-                                and every env's wave waits for that env's previous step (a per-env counter in device memory) instead
-                                of the whole previous launch -- step k+1 starts env by env while step k's slower envs are still at
-                                work.  Same launches, same results.  Honoured when a map-specific uint8 kernel runs (the shipped
-                                and the enlarged maps), ring >= 2 (consecutive steps must not share an output slot) and two launches' waves fit on
-                                the device with a fifth of it to spare (up to ~3200 envs of the shipped maps on MI355X); ignored otherwise, and while another handle's
-                                pipelined rollout is in flight on the device.  It pays while the
-                                device has room to spare: 2048 envs 5.7 -> 4.8 us per step, no gain at 4096.  A wave that waits in
-                                vain (tens of ms: the device is oversubscribed by other work) sets SSD_ST_PIPE_TIMEOUT.
-                                The room-to-spare rule counts ONE process: the request is meant for a process that has the device to
-                                itself.  Other processes' kernels on the same device only delay the waves (tested: a second process
-                                stepping 4096 envs throughout leaves the results bit-exact and the status word 0); what would starve
-                                them is another process pinning most of the device's wave slots with kernels that themselves wait --
-                                the bounded wait and the status bit are the guard against that, not a proof. */
+    /* (1u << 5 was SSD_ROLLOUT_PIPELINED, rounds 1-2: launches of consecutive steps overlapped through per-env pass counters.
+       It bought nothing once the library dispatched through its own queues -- 4.44 against 4.50 us per step at 2048 envs -- and
+       was the one mode in which kernels waited on other kernels' flags: removed.  The bit is ignored.) */
+    SSD_STEP_CHAINS = 1u << 6, /* ssd_step only: dispatch the step the way a one-step ssd_rollout_actions call is dispatched -- env
+                                ranges stepped concurrently through the library's own queues, forked from and joined into `stream`.
+                                Device pointers, order == NULL, no SSD_AUTO_RESET.  Same results as the plain call.  Whether it
+                                pays depends on the batch: a single launch has no chain of dependent launches to hide, and the
+                                fork / join cost ~20 us per call (bench.py: policy_step) */
     SSD_OBS_F32 = 1u << 2    /* obs points at float32 [E,N,V,V,3] instead of uint8: the normalisation of map_env.py:199
                                 fused into the kernel (4x the observation bytes; a separate, slower mode) */
 };
@@ -83,7 +77,9 @@ enum {
     SSD_ST_BAD_ACTION = 1u << 0,  /* action id outside the game's Discrete(n): KeyError in agent.action_map */
     SSD_ST_NO_SPAWN = 1u << 1,    /* not enough spawn points (assert at map_env.py:661) */
     SSD_ST_MOVE_LOOKUP = 1u << 2, /* agent_by_pos lookup miss (would be a KeyError at map_env.py:506) */
-    SSD_ST_PIPE_TIMEOUT = 1u << 3 /* SSD_ROLLOUT_PIPELINED: a wave gave up waiting for its env's previous step; results are invalid */
+    SSD_ST_WAIT_TIMEOUT = 1u << 3 /* a rollout call's stream-side wait for the library's queues gave up (seconds: the queues' kernels
+                                     never ran -- e.g. a tool that runs kernels one at a time, attached in a way the library did not
+                                     notice); the call's outputs are not in place.  See SSD_AQL_SYNC below */
 };
 
 typedef struct ssd_env ssd_env;
@@ -145,20 +141,70 @@ int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, voi
 int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32_t reset_every, int32_t step0,
                        void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream);
 
-/* How the last ssd_rollout_random call of the handle was dispatched (a bit mask; 0 before the first call):
+/* The same call with CALLER-SUPPLIED actions -- what the reference's real callers do: env.step(policy actions)
+ * (visuallizer_rllib.py:121-153; RLlib's sampler behind train_baseline.py:71-81), map_env.py:152-212 per step -- for open-loop
+ * replay of recorded action sequences, action chunking, or a policy that emits several steps at once.
+ *   actions i32 [action_ring,E,N] (device): step k of the call reads slot (step0 + k) % action_ring; -1 = the agent does not act.
+ *           action_ring = n_steps with step0 = 0 is the plain [K,E,N] form; action_ring = 1 feeds every step the same actions.
+ *   order   u8  [action_ring,E,N] (device) or NULL: per step, the agent indices in action-dict order, 0xFF-terminated, as ssd_step
+ *           takes them; NULL = index order (what the map-specific kernels and the coherent chains need: an explicit order takes
+ *           the general kernels).
+ * Everything else -- resets, output ring, chains, flags (SSD_ROLLOUT_FUSED: one launch, the actions fetched a step ahead;
+ * SSD_OBS_F32) -- as ssd_rollout_random, and dispatched the same way: the step launches' kernel arguments are static per
+ * (output slot, action slot) pair, so a call enqueues 64-byte packets only (argument sets are cached by the buffers passed: reuse
+ * the same action / output buffers from call to call; more than 2048 / chains distinct (slot, slot) pairs go through HIP streams).
+ * The actions must be in place on `stream` before the call (the call orders itself after the stream's earlier work) and must not
+ * change until the call's work has completed on `stream`.  An action outside the game's Discrete(n) sets SSD_ST_BAD_ACTION. */
+int ssd_rollout_actions(ssd_env *env, const int32_t *actions, const uint8_t *order, int32_t action_ring, int32_t n_steps,
+                        int32_t reset_every, int32_t step0, void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags,
+                        void *stream);
+
+/* How the last rollout call (ssd_rollout_random / ssd_rollout_actions / ssd_step with SSD_STEP_CHAINS) of the handle was
+ * dispatched (a bit mask; 0 before the first call):
  *   SSD_PATH_AQL       the launches were written as AQL packets into the library's own queues (else: hipLaunchKernel)
  *   SSD_PATH_COHERENT  ... with the kernel variant that needs no cache write-back between a chain's launches
  *   SSD_PATH_SPLIT     ... and every step's observations rendered by extra workgroups of the next step's launch
- *   SSD_PATH_FUSED / SSD_PATH_PIPELINED   the call ran as the fused rollout kernel / with pipelined launches
- *   bits 8..11         number of chains
+ *   SSD_PATH_FUSED     the call ran as the fused rollout kernel
+ *   SSD_PATH_SYNC      ... with host-side waits instead of waiting kernels (a profiling tool is attached, or SSD_AQL_SYNC=1)
+ *   SSD_PATH_FORKED    ... behind a fork from `stream`, which had work pending when the call came
+ *   SSD_PATH_QUEUE_DROPPED  a dispatch queue of the device's pool failed its probe and was destroyed again (the rule below)
+ *   bits 8..11         number of chains        bits 12..14  dispatch queues the device's pool has settled on
  * So that a caller (a test, a benchmark) can tell a silent fallback from the path it meant to measure. */
-enum { SSD_PATH_AQL = 1, SSD_PATH_COHERENT = 2, SSD_PATH_SPLIT = 4, SSD_PATH_FUSED = 8, SSD_PATH_PIPELINED = 16 };
+enum { SSD_PATH_AQL = 1, SSD_PATH_COHERENT = 2, SSD_PATH_SPLIT = 4, SSD_PATH_FUSED = 8, SSD_PATH_SYNC = 16, SSD_PATH_QUEUE_DROPPED = 32,
+       SSD_PATH_FORKED = 64 };
 int ssd_rollout_path(const ssd_env *env);
 
-/* Number of chains ssd_rollout_random uses: 1..8, or 0 = automatic (1 below 2048 envs, 3 from 6144 to 24576, else 2 -- and never
- * more than the library has dispatch queues of its own: 3 per device, or 4 - GPU_MAX_HW_QUEUES when the process sets that
- * variable for the HIP runtime: a process has about four hardware queues before the device time-slices them). */
+/* Number of chains the rollout calls use: 1..8, or 0 = automatic (1 below 2048 envs, 3 from 6144 to 24576, else 2 -- and never
+ * more than the device's pool has dispatch queues).
+ *
+ * THE QUEUE RULE.  A process has about four hardware queues before the device time-slices them, and past that EVERY kernel launch
+ * of the process -- the host application's too -- takes ~30 us.  The HIP runtime takes up to GPU_MAX_HW_QUEUES of them (default 4,
+ * one per stream in use), RCCL one more stream.  So: the library's pool holds SSD_AQL_QUEUES queues (1..3) if that is set; else
+ * 4 - GPU_MAX_HW_QUEUES if the process sets that variable for the HIP runtime (at least 1); else 2.  And whatever the rule says,
+ * every queue is PROBED when it is created (first rollout call that needs it; the device is synchronised once): a burst of one-wave
+ * dispatches on the new queue and a burst of HIP launches on the null stream, against the figures from before the pool grew.  A
+ * queue whose arrival makes either burst more than 2.5 x (+ 20 us) slower is destroyed again and the pool stays at the size that
+ * was fine for the life of the process (SSD_PATH_QUEUE_DROPPED, bits 12..14 of ssd_rollout_path); a call that asked for more
+ * chains goes through HIP streams.  Streams the host application creates LATER are not seen by the probe: an application that
+ * knows it will hold many should set SSD_AQL_QUEUES=1 or SSD_AQL=0.
+ *
+ * ENVIRONMENT (read once per process; these are all the variables the product library reads):
+ *   SSD_AQL=0            no dispatch queues of the library's own: every launch through hipLaunchKernel
+ *   SSD_AQL_QUEUES=n     size of the pool (1..3), see above
+ *   SSD_AQL_COHERENT=0   plain kernels behind agent-scope fences instead of the coherent variant
+ *   SSD_AQL_SPLIT=0      every step renders its own observations
+ *   SSD_AQL_SYNC=1 / 0   host-side waits instead of waiting kernels: forced / forbidden (default: on when a profiling tool
+ *                        is attached -- ssd_profiler_attached() -- because such tools may run kernels one at a time)
+ *   SSD_AQL_VERBOSE=1    the dispatch layer says on stderr what it set up (agent match, probe figures, fallbacks)
+ *   SSD_ROLLOUT_CHAINS=n chains of the rollout calls when ssd_set_rollout_chains is 0
+ *   SSD_ENVS_PER_BLOCK=n envs (waves) per workgroup, 1..16
+ * Nothing here changes results.  The knobs that CAN (fence scopes, alternating geometries, forced forks) exist only in the
+ * test-hook build, libssd_hip_testhooks.so (make testhooks), which the product never loads. */
 int ssd_set_rollout_chains(ssd_env *env, int32_t chains);
+
+/* 1 when a profiling / tracing tool is attached to the process (the ROCm tools' environment variables, or their libraries
+ * loaded): the rollout calls then use host-side waits (SSD_PATH_SYNC).  Needs no device. */
+int ssd_profiler_attached(void);
 
 /* Observation of the current state without stepping (the per-agent part of map_env.py:189-199). */
 int ssd_observe(ssd_env *env, void *obs, uint32_t flags, void *stream);

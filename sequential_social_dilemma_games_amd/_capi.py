@@ -7,17 +7,19 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# SSD_LIB_PATH lets tools/phase_profile.py load the diagnostic (stamped) build of the SAME sources.
+# SSD_LIB_PATH lets tools/phase_profile.py load the diagnostic (stamped) build of the SAME sources, and the tests that need
+# test hooks the test-hook build (libssd_hip_testhooks.so: the product sources with -DSSD_TESTHOOKS).
 LIB_PATH = os.environ.get("SSD_LIB_PATH") or os.path.join(_PKG, "libssd_hip.so")
 
 SSD_OK, SSD_E_INVALID, SSD_E_DEVICE, SSD_E_NOMEM, SSD_E_STATE = 0, -1, -2, -3, -4
-SSD_HOST_PTRS, SSD_NO_ROTATE, SSD_OBS_F32, SSD_ROLLOUT_FUSED, SSD_AUTO_RESET, SSD_ROLLOUT_PIPELINED = 1, 2, 4, 8, 16, 32
-SSD_PATH_AQL, SSD_PATH_COHERENT, SSD_PATH_SPLIT, SSD_PATH_FUSED, SSD_PATH_PIPELINED = 1, 2, 4, 8, 16
-SSD_ST_BAD_ACTION, SSD_ST_NO_SPAWN, SSD_ST_MOVE_LOOKUP, SSD_ST_PIPE_TIMEOUT = 1, 2, 4, 8
-ABI_VERSION = 1
+SSD_HOST_PTRS, SSD_NO_ROTATE, SSD_OBS_F32, SSD_ROLLOUT_FUSED, SSD_AUTO_RESET, SSD_STEP_CHAINS = 1, 2, 4, 8, 16, 64
+SSD_PATH_AQL, SSD_PATH_COHERENT, SSD_PATH_SPLIT, SSD_PATH_FUSED, SSD_PATH_SYNC, SSD_PATH_QUEUE_DROPPED, SSD_PATH_FORKED = 1, 2, 4, 8, 16, 32, 64
+SSD_ST_BAD_ACTION, SSD_ST_NO_SPAWN, SSD_ST_MOVE_LOOKUP, SSD_ST_WAIT_TIMEOUT = 1, 2, 4, 8
+ABI_VERSION = 2
 
 # every symbol include/ssd.h declares
-SYMBOLS = ("ssd_create", "ssd_destroy", "ssd_reset", "ssd_step", "ssd_step_random", "ssd_rollout_random", "ssd_rollout_path", "ssd_set_rollout_chains", "ssd_observe",
+SYMBOLS = ("ssd_create", "ssd_destroy", "ssd_reset", "ssd_step", "ssd_step_random", "ssd_rollout_random", "ssd_rollout_actions", "ssd_rollout_path", "ssd_set_rollout_chains",
+           "ssd_profiler_attached", "ssd_observe",
            "ssd_get_state", "ssd_set_state", "ssd_get_waste_count", "ssd_render_full", "ssd_render_frames", "ssd_agent_action_obs", "ssd_set_horizon", "ssd_potential_waste_area",
            "ssd_device_status", "ssd_synchronize", "ssd_last_error", "ssd_abi_version")
 
@@ -80,6 +82,8 @@ def lib():
         L.ssd_step.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp]
         L.ssd_step_random.argtypes = [vp, i32, vp, vp, vp, vp, u32, vp]
         L.ssd_rollout_random.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, i32, u32, vp]
+        L.ssd_rollout_actions.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, u32, vp]
+        L.ssd_profiler_attached.argtypes = []
         L.ssd_rollout_path.argtypes = [vp]
         L.ssd_set_rollout_chains.argtypes = [vp, i32]
         L.ssd_observe.argtypes = [vp, vp, u32, vp]

@@ -22,7 +22,10 @@
 // writes for its own kernel packets; none for the coherent kernel variants).
 //
 // Nothing here computes anything: if the HSA runtime, a queue or the code object cannot be set up, aql::available() is false
-// and ssd_rollout_random issues the same launches through hipLaunchKernel.  SSD_AQL=0 forces that.
+// and the rollout calls issue the same launches through hipLaunchKernel.  SSD_AQL=0 forces that.
+// Queues are a scarce, process-wide resource (below, "the cliff"): every queue of the pool is PROBED when it is created -- a burst of
+// one-wave dispatches on it and a burst of HIP launches on a stream, against the figures measured before the pool existed -- and a
+// queue whose arrival slows either down is destroyed again; the pool then stays at the size that was fine.
 #include <hip/hip_runtime.h>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
@@ -30,7 +33,9 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -61,6 +66,9 @@ namespace {
     X(hsa_signal_wait_scacquire)
 
 constexpr int kPoolQueues = 3;
+#ifndef SSD_ARCH
+#define SSD_ARCH "gfx950"                                   // (the Makefile passes its ARCH)
+#endif
 
 struct Api {
 #define X(f) decltype(&::f) f = nullptr;
@@ -82,6 +90,13 @@ struct DeviceCtx {
     std::mutex enqueue_mu;                                // one rollout call writes packets at a time
     uint32_t *abort_host = nullptr;                       // host memory (device-mapped): a queue of the device reported an error
     void *abort_dev = nullptr;
+    // the probe (probe_pool_queue): what a burst of HIP launches / of dispatches on a pool queue cost before the pool grew
+    unsigned long long *probe_counter = nullptr;          // device memory the probe's one-wave dispatches bump
+    void *probe_kernarg = nullptr;
+    double hip_burst_base_us = 0, hip_burst_last_us = 0, q_burst_base_us = 0, q_burst_last_us = 0;
+    int pool_cap = kPoolQueues;                           // shrinks when a new queue fails its probe
+    int dropped = 0;                                      // queues destroyed again by the probe
+    const char *matched_by = "";                          // how the HSA agent was matched to the HIP device
 };
 std::mutex g_mu;
 bool g_api_tried = false, g_api_ok = false;
@@ -110,7 +125,12 @@ bool load_api() {
     return true;
 }
 
-struct AgentSearch { uint32_t want_bdf, want_domain; bool found; hsa_agent_t gpu; bool have_cpu; hsa_agent_t cpu; };
+struct AgentSearch {
+    uint32_t want_bdf, want_domain; bool found; hsa_agent_t gpu; bool have_cpu; hsa_agent_t cpu;
+    // second and third chance: the agent whose UUID string ("GPU-<16 hex digits>") HIP reports for the device; the n-th GPU agent
+    char want_uuid[24]; bool found_uuid; hsa_agent_t gpu_uuid;
+    int want_ordinal, seen_gpus; bool found_ordinal; hsa_agent_t gpu_ordinal;
+};
 hsa_status_t agent_cb(hsa_agent_t a, void *data) {
     auto *s = static_cast<AgentSearch *>(data);
     hsa_device_type_t type;
@@ -121,6 +141,11 @@ hsa_status_t agent_cb(hsa_agent_t a, void *data) {
     g_api.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
     g_api.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
     if (!s->found && bdf == s->want_bdf && domain == s->want_domain) { s->gpu = a; s->found = true; }
+    char uuid[64] = {};
+    if (!s->found_uuid && s->want_uuid[0] && g_api.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_UUID, uuid) == HSA_STATUS_SUCCESS &&
+        std::strncmp(uuid, s->want_uuid, sizeof(s->want_uuid)) == 0) { s->gpu_uuid = a; s->found_uuid = true; }
+    if (!s->found_ordinal && s->seen_gpus == s->want_ordinal) { s->gpu_ordinal = a; s->found_ordinal = true; }
+    s->seen_gpus++;
     return HSA_STATUS_SUCCESS;
 }
 hsa_status_t pool_cb(hsa_amd_memory_pool_t pool, void *data) {
@@ -156,7 +181,7 @@ bool find_code_object(const unsigned char **co, size_t *size) {
         if (pos + tl > n) return false;
         const std::string triple(reinterpret_cast<const char *>(b + pos), (size_t)tl);
         pos += tl;
-        if (triple.find("amdgcn-amd-amdhsa") != std::string::npos && triple.find("gfx950") != std::string::npos && off + sz <= n && sz > 0) {
+        if (triple.find("amdgcn-amd-amdhsa") != std::string::npos && triple.find(SSD_ARCH) != std::string::npos && off + sz <= n && sz > 0) {
             *co = b + off; *size = (size_t)sz;
             return true;
         }
@@ -170,7 +195,7 @@ DeviceCtx *device_ctx(int device) {
     DeviceCtx &c = g_dev[device];
     if (c.tried) return c.ok ? &c : nullptr;
     c.tried = true; c.device = device;
-    static const bool off = [] { const char *v = getenv("SSD_AQL"); return v && atoi(v) == 0; }();
+    static const bool off = SSD_KNOB("SSD_AQL", 1) == 0;
     if (off) { c.why = "SSD_AQL=0"; return nullptr; }
     if (!load_api()) { c.why = "HSA runtime unavailable"; return nullptr; }
     auto fail = [&](const std::string &m) -> DeviceCtx * { c.why = m; say(m); return nullptr; };
@@ -182,12 +207,26 @@ DeviceCtx *device_ctx(int device) {
         return fail("cannot read the device's PCI address");
     AgentSearch s{};
     s.want_domain = (uint32_t)dom;
+    {   // (HIP's 16-byte device uuid is the hex digits of the HSA agent's "GPU-<hex>" string)
+        hipUUID u{};
+        if (hipDeviceGetUuid(&u, device) == hipSuccess && u.bytes[0]) {
+            std::memcpy(s.want_uuid, "GPU-", 4);
+            std::memcpy(s.want_uuid + 4, u.bytes, 16);
+        }
+        (void)hipGetLastError();
+        // (the n-th GPU agent is the HIP device n only while nothing filters or reorders the devices HIP shows)
+        const bool filtered = getenv("HIP_VISIBLE_DEVICES") || getenv("CUDA_VISIBLE_DEVICES");
+        s.want_ordinal = filtered ? -1 : device;
+    }
     for (uint32_t fn = 0; fn < 8 && !s.found; ++fn) {       // BDFID = bus << 8 | device << 3 | function
         s.want_bdf = ((uint32_t)bus << 8) | ((uint32_t)dev << 3) | fn;
-        s.have_cpu = false;
+        s.have_cpu = false; s.seen_gpus = 0;
         g_api.hsa_iterate_agents(agent_cb, &s);
     }
-    if (!s.found || !s.have_cpu) return fail("no HSA agent matches the HIP device's PCI address");
+    c.matched_by = "PCI address";
+    if (!s.found && s.found_uuid) { s.gpu = s.gpu_uuid; s.found = true; c.matched_by = "UUID"; }
+    if (!s.found && s.found_ordinal) { s.gpu = s.gpu_ordinal; s.found = true; c.matched_by = "ordinal"; }
+    if (!s.found || !s.have_cpu) return fail("no HSA agent matches HIP device " + std::to_string(device) + " (PCI address, UUID, ordinal)");
     c.gpu = s.gpu; c.cpu = s.cpu;
     c.host_kernarg_pool.handle = 0;
     g_api.hsa_amd_agent_iterate_memory_pools(c.cpu, pool_cb, &c.host_kernarg_pool);
@@ -204,7 +243,7 @@ DeviceCtx *device_ctx(int device) {
     st = g_api.hsa_executable_freeze(c.exe, nullptr);
     if (st != HSA_STATUS_SUCCESS) return fail("hsa_executable_freeze failed");
     c.ok = true;
-    say("device " + std::to_string(device) + ": own AQL dispatch path ready");
+    say("device " + std::to_string(device) + ": own AQL dispatch path ready (HSA agent matched by " + c.matched_by + ")");
     return &c;
 }
 
@@ -279,7 +318,7 @@ static void queue_destroy(Queue *Q) {
 static Queue *queue_create(DeviceCtx *c) {
     Queue *Q = new Queue();
     Q->ctx = c;
-    static const uint32_t qsize = [] { const char *v = getenv("SSD_AQL_QUEUE_SIZE"); int n = v ? atoi(v) : 4096; return (uint32_t)(n >= 64 ? n : 4096); }();
+    static const uint32_t qsize = [] { const int n = SSD_HOOK("SSD_AQL_QUEUE_SIZE", 4096); return (uint32_t)(n >= 64 ? n : 4096); }();
     uint32_t size = 64;
     while (size < qsize) size <<= 1;
     // (a process's total matters: with 4 queues of the library's beside the HIP runtime's -- even idle ones -- every launch of the
@@ -302,10 +341,88 @@ static Queue *queue_create(DeviceCtx *c) {
     return Q;
 }
 
-// Queue `index` (0 .. pool_size() - 1) of the device's pool, created on first use; nullptr if that fails.
+// How many queues of its own the library may hold.  A process gets about FOUR hardware queues before the hardware scheduler starts
+// time-slicing them (every dispatch then waits for its queue's turn: a 20-step rollout that follows an RCCL barrier 320 us instead of
+// 130; measured: the HIP runtime's queues in use + the library's = 4 fine, 5 not -- with 4 queues of the library's beside the
+// runtime's, idle ones included, EVERY launch of the process slowed to ~30 us).  The HIP runtime maps its streams onto at most
+// GPU_MAX_HW_QUEUES queues (default 4, created as streams need them).  The rule (documented in include/ssd.h):
+//   * SSD_AQL_QUEUES (1..3) sets the pool's size;
+//   * else a process that sets GPU_MAX_HW_QUEUES -- bench.py does, to 2, as a rank of a process group -- has told us how many the
+//     runtime takes: the pool gets 4 minus that, at least 1;
+//   * else TWO: a host application with a few torch streams and RCCL's has room for them, not for three;
+//   * and whatever the rule says, a queue that fails its probe when it is created (below) is destroyed again and the pool stays
+//     at the size that was fine (pool_size(device)).
+static int pool_limit() {
+    static const int n = [] {
+        int v = 2;
+        if (const char *h = getenv("GPU_MAX_HW_QUEUES")) { const int hq = atoi(h); if (hq >= 1) v = 4 - hq; }
+        if (const char *o = getenv("SSD_AQL_QUEUES")) v = atoi(o);
+        return v < 1 ? 1 : v > kPoolQueues ? kPoolQueues : v;
+    }();
+    return n;
+}
+int pool_size(int device) {
+    if (device < 0 || device >= 64) return 1;
+    const int cap = g_dev[device].pool_cap < pool_limit() ? g_dev[device].pool_cap : pool_limit();
+    return cap < 1 ? 1 : cap;
+}
+
+static double now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+// A burst of one-wave dispatches (barrier bit: one after the other) on Q, host-waited; microseconds, < 0 on failure.
+static double queue_burst_us(DeviceCtx *c, Queue *Q, int n) {
+    if (!Q->done_signal.handle || !c->probe_kernarg) return -1;
+    const double t0 = now_us();
+    for (int i = 0; i < n - 1; ++i) dispatch(Q, Q->flag_kernel, 1, 64, 0, c->probe_kernarg, true, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE);
+    if (!join_and_wait(Q, c->probe_kernarg)) return -1;
+    return now_us() - t0;
+}
+// A burst of one-wave HIP launches on the null stream + synchronize; microseconds, < 0 on failure.
+static double hip_burst_us(int n) {
+    static long long *scratch = [] { void *ptr = nullptr; if (hipMalloc(&ptr, 8) != hipSuccess) ptr = nullptr; return static_cast<long long *>(ptr); }();
+    if (!scratch) return -1;
+    const double t0 = now_us();
+    for (int i = 0; i < n; ++i) launch_signal_kernel(scratch, nullptr);
+    if (hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return now_us() - t0;
+}
+// THE PROBE.  Called with the device idle (the first rollout call of a handle synchronises anyway).  Before the pool's first queue
+// exists it records what a burst of HIP launches costs; after every new queue it measures that burst again and a burst of dispatches
+// on the new queue (against the first queue's own figure).  Past the cliff BOTH are an order of magnitude off (every dispatch waits
+// for its queue's time slice), so the thresholds need no tuning: 2.5 x the base figure plus 20 us (medians of 3 bursts of 16).
+// Returns false when the new queue must go.
+static constexpr int kBurst = 16, kBurstReps = 3;
+static double median3(double (*f)(DeviceCtx *, Queue *), DeviceCtx *c, Queue *Q) {
+    double v[kBurstReps];
+    for (double &x : v) x = f(c, Q);
+    std::sort(v, v + kBurstReps);
+    return v[0] < 0 ? -1 : v[kBurstReps / 2];
+}
+static bool probe_pool_queue(DeviceCtx *c, Queue *Q, int index) {
+    static const bool probe_on = SSD_HOOK("SSD_AQL_PROBE", 1) != 0;
+    if (!probe_on) return true;
+    auto hipb = [](DeviceCtx *, Queue *) { return hip_burst_us(kBurst); };
+    auto qb = [](DeviceCtx *cc, Queue *q) { return queue_burst_us(cc, q, kBurst); };
+    (void)queue_burst_us(c, Q, 2);                        // (first dispatches of a new queue: not timed)
+    const double q_us = median3(qb, c, Q), h_us = median3(hipb, c, nullptr);
+    c->q_burst_last_us = q_us; c->hip_burst_last_us = h_us;
+    if (index == 0) c->q_burst_base_us = q_us;
+    char msg[256];
+    snprintf(msg, sizeof msg, "probe: queue %d: %d dispatches %.1f us (first queue %.1f), %d HIP launches %.1f us (before the pool %.1f)", index, kBurst,
+             q_us, c->q_burst_base_us, kBurst, h_us, c->hip_burst_base_us);
+    say(msg);
+    if (q_us < 0 || h_us < 0 || c->hip_burst_base_us <= 0) return true;           // (no figures: no verdict)
+    const bool hip_slow = h_us > 2.5 * c->hip_burst_base_us + 20.0;
+    const bool q_slow = index > 0 && c->q_burst_base_us > 0 && q_us > 2.5 * c->q_burst_base_us + 20.0;
+    return !(hip_slow || q_slow);
+}
+
+// Queue `index` (0 .. pool_size(device) - 1) of the device's pool, created -- and probed -- on first use; nullptr if that fails or
+// the probe turns the queue down (the pool then stays smaller for the life of the process).
 Queue *pool_queue(int device, int index) {
     DeviceCtx *c = device_ctx(device);
-    if (!c || index < 0 || index >= pool_size()) return nullptr;
+    if (!c || index < 0 || index >= pool_size(device)) return nullptr;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if (!c->abort_host) {
@@ -316,25 +433,53 @@ Queue *pool_queue(int device, int index) {
         }
         if (c->pool[index]) return c->pool[index];
     }
+    std::lock_guard<std::mutex> probe_lk(c->enqueue_mu);            // (one creation + probe at a time; nobody writes packets meanwhile)
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (c->pool[index]) return c->pool[index];
+        if (index >= (c->pool_cap < pool_limit() ? c->pool_cap : pool_limit())) return nullptr;
+    }
+    if (!c->probe_counter) {
+        void *ptr = nullptr;
+        if (hipMalloc(&ptr, 8) == hipSuccess && hipMemset(ptr, 0, 8) == hipSuccess) {
+            c->probe_counter = static_cast<unsigned long long *>(ptr);
+            c->probe_kernarg = host_kernarg_alloc(device, 64);
+            if (c->probe_kernarg) std::memcpy(c->probe_kernarg, &c->probe_counter, sizeof(void *));
+        }
+        (void)hipGetLastError();
+        // what HIP launches cost in this process before the library holds any queue of its own
+        (void)hip_burst_us(2);
+        double v[kBurstReps];
+        for (double &x : v) x = hip_burst_us(kBurst);
+        std::sort(v, v + kBurstReps);
+        c->hip_burst_base_us = v[0] < 0 ? 0 : v[kBurstReps / 2];
+    }
     Queue *Q = queue_create(c);                     // (takes g_mu itself, in lookup())
+    if (Q && !probe_pool_queue(c, Q, index)) {
+        say("queue " + std::to_string(index) + " slows the process down (hardware-queue cliff): destroyed, the pool stays at " + std::to_string(index));
+        if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+        queue_destroy(Q);
+        Q = nullptr;
+        std::lock_guard<std::mutex> lk(g_mu);
+        c->pool_cap = index;
+        c->dropped++;
+        // (not even one queue of the library's fits beside what the process already holds: no own dispatch path on this device,
+        // the rollout calls go through hipLaunchKernel)
+        if (index == 0) { c->ok = false; c->why = "the first dispatch queue already slows the process's launches down"; }
+        return nullptr;
+    }
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!c->pool[index]) c->pool[index] = Q;
-    else if (Q) queue_destroy(Q);                   // (another thread was faster)
-    return c->pool[index];
+    c->pool[index] = Q;
+    return Q;
 }
-// How many queues of its own the library may hold.  A process gets about FOUR hardware queues before the hardware scheduler starts
-// time-slicing them (every dispatch then waits for its queue's turn: a 20-step rollout that follows an RCCL barrier 320 us instead of
-// 130; measured: the HIP runtime's queues in use + the library's = 4 fine, 5 not).  The HIP runtime maps its streams onto at most
-// GPU_MAX_HW_QUEUES queues (default 4, created as streams need them): a process that sets it -- bench.py does, to 2 -- tells us
-// how many are left; unset, a plain torch process uses one or two and the pool takes three.  SSD_AQL_QUEUES (1..3) overrides.
-int pool_size() {
-    static const int n = [] {
-        int v = kPoolQueues;
-        if (const char *h = getenv("GPU_MAX_HW_QUEUES")) { const int hq = atoi(h); if (hq >= 1) v = 4 - hq; }
-        if (const char *o = getenv("SSD_AQL_QUEUES")) v = atoi(o);
-        return v < 1 ? 1 : v > kPoolQueues ? kPoolQueues : v;
-    }();
-    return n;
+// bits for ssd_rollout_path(): the size the pool settled on (<< 12) | "a queue failed its probe and was destroyed" (32)
+int pool_report(int device) {
+    if (device < 0 || device >= 64) return 0;
+    return (pool_size(device) << 12) | (g_dev[device].dropped ? 32 : 0);
+}
+void probe_figures(int device, double out[4]) {
+    const DeviceCtx &c = g_dev[device];
+    out[0] = c.hip_burst_base_us; out[1] = c.hip_burst_last_us; out[2] = c.q_burst_base_us; out[3] = c.q_burst_last_us;
 }
 std::mutex &enqueue_mutex(int device) { return g_dev[device].enqueue_mu; }
 const uint32_t *abort_flag_dev(int device) { return static_cast<const uint32_t *>(g_dev[device].abort_dev); }

@@ -14,11 +14,13 @@ bool available(int device);                        // HSA runtime reachable, age
 const char *why_not(int device);
 bool lookup(int device, const void *host_fn, Kernel *out);   // kernel descriptor of the instantiation behind a HIP host stub
 
-// The device's dispatch queues: a pool of at most pool_size() queues per device, shared by every handle on it (queues are
-// scarce: ssd_aql.hip), created on first use and kept for the life of the process.  One rollout call writes packets at a time
-// (enqueue_mutex).
+// The device's dispatch queues: a pool of at most pool_size(device) queues per device, shared by every handle on it (queues are
+// scarce: ssd_aql.hip), created -- and probed for the hardware-queue cliff -- on first use and kept for the life of the process.
+// One rollout call writes packets at a time (enqueue_mutex).
 Queue *pool_queue(int device, int index);
-int pool_size();
+int pool_size(int device);                         // what the rule of include/ssd.h allows, less what the probe turned down
+int pool_report(int device);                       // bits for ssd_rollout_path(): pool_size << 12 | 32 if the probe dropped a queue
+void probe_figures(int device, double out[4]);     // us: HIP burst before the pool / after its last queue, queue burst first / last
 std::mutex &enqueue_mutex(int device);
 bool queue_failed(const Queue *q);                 // the runtime reported an error on the queue (the path is then abandoned)
 uint64_t write_index(const Queue *q);              // index the next packet will get

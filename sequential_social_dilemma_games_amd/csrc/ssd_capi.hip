@@ -4,6 +4,8 @@
 // path exists here: every stepping call ends in a kernel launch or an error code.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -26,15 +28,18 @@ using ssd::Params;
 
 static thread_local std::string g_create_error;
 
-// One persistent host thread per extra rollout chain (ssd_rollout_random).  Created on the first multi-chain call, bound
+// One persistent host thread per extra rollout chain (ssd_rollout_random / ssd_rollout_actions through HIP streams).  Created on the first multi-chain call, bound
 // to the handle's device once, then parked: a job is handed over through `state` (0 idle, 1 posted, 2 finished, 3 quit).
 // After a job the thread keeps polling for the next one for a short while before it sleeps on the condition variable, so a
 // loop of short rollout calls (rollout.py:58-70 called per training iteration) pays neither a thread creation + per-thread
 // HIP initialisation (~250 us per call: round 1) nor a futex wake-up per call.
 struct ChainJob {
-    bool pipelined = false;
     int chain = 0, e_begin = 0, e_end = 0;
     int32_t num_actions = 0, n_steps = 0, reset_every = 0, step0 = 0, ring = 1;
+    // caller-supplied actions (ssd_rollout_actions): i32 [action_ring][E][N], step k reads slot (step0 + k) % action_ring;
+    // null: every step draws its actions on the device (ssd_rollout_random)
+    const int32_t *actions = nullptr; int32_t action_ring = 0;
+    const uint8_t *order = nullptr;                  // [action_ring][E][N] action-dict orders (null: index order), same slots
     uint8_t *obs = nullptr; int32_t *rew = nullptr; uint8_t *done = nullptr;
     uint32_t flags = 0;
     hipStream_t s = nullptr;
@@ -65,18 +70,21 @@ struct AqlState {
     struct Key {
         const void *obs = nullptr, *rew = nullptr, *done = nullptr;
         int32_t ring = 0, f32 = 0, num_actions = 0, chains = 0, horizon = 0, coherent = 0, split = 0;
+        const void *actions = nullptr, *order = nullptr; int32_t action_ring = 0;  // caller-supplied actions: part of every step launch's arguments
+        int32_t slots = 0;                                       // argument blocks per chain and kind: lcm(ring, action_ring)
         const void *stamps = nullptr; uint32_t dbg_skip = 0;     // (diagnostic builds: part of the kernel arguments too)
         const void *world = nullptr;                             // sets that are not split: the state buffer their blocks name
         bool operator==(const Key &o) const {
             return stamps == o.stamps && dbg_skip == o.dbg_skip && world == o.world && obs == o.obs && rew == o.rew && done == o.done && ring == o.ring && f32 == o.f32 && num_actions == o.num_actions &&
-                   chains == o.chains && horizon == o.horizon && coherent == o.coherent && split == o.split;
+                   chains == o.chains && horizon == o.horizon && coherent == o.coherent && split == o.split && actions == o.actions && order == o.order &&
+                   action_ring == o.action_ring && slots == o.slots;
         }
     };
     struct Geo { ssd::aql::Kernel k; uint32_t grid_x = 0, block_x = 0, lds = 0; };
     struct Set {
         bool valid = false;
         Key key;
-        uint8_t *dev = nullptr;                     // [chains][ring][kKinds] blocks of kBlock bytes
+        uint8_t *dev = nullptr;                     // [chains][slots][kKinds] blocks of kBlock bytes
         size_t cap = 0;
         Geo geo[8][12];                             // per chain and kind (kKinds: asserted below)
         uint64_t last_use[8] = {};                  // index of the last join packet after a use, per chain (+1)
@@ -121,12 +129,6 @@ struct ssd_env {
     std::vector<hipStream_t> chain_streams;
     std::vector<hipEvent_t> chain_events;
     hipEvent_t fork_event = nullptr;
-    hipEvent_t pipe_done = nullptr;   // recorded after this handle's last pipelined rollout
-    // pipelined rollouts: per-env pass counters, and per chain a second stream (launches alternate) with its events
-    uint32_t *pipe_flags = nullptr;
-    struct ChainPipe { hipStream_t sb = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr; };
-    ChainPipe chain_pipe[8];
-    int wave_slots = 0;               // resident waves the device can hold (CUs x 32)
     int rollout_chains = 0;           // 0 = automatic
     std::vector<std::unique_ptr<ChainWorker>> workers;   // workers[c - 1] enqueues chain c
     std::unique_ptr<AqlState> aql;                       // the library's own dispatch path (ssd_aql.hip), set up on first use
@@ -135,16 +137,11 @@ struct ssd_env {
     // mixes the two styles -- tensors on a non-blocking side stream, then a *_host call -- gets program order.
     hipStream_t last_stream = nullptr;
     bool last_stream_set = false;
-    int last_path = 0;                                   // SSD_PATH_* of the last ssd_rollout_random call
+    int last_path = 0;                                   // SSD_PATH_* of the last rollout call
     std::string err;
 };
 
 namespace {
-
-// One pipelined rollout per device at a time (within this process): the room-to-spare rule of ssd_rollout_random counts one
-// handle's launches.  A handle asking while another handle's pipelined rollout is still in flight gets plain launches.
-struct PipeOwners { std::mutex mu; ssd_env *owner[64] = {}, *enqueuing[64] = {}; hipEvent_t done[64] = {}; };
-PipeOwners g_pipe_owners;
 
 #define SSD_HIP(env, call)                                                                      \
     do {                                                                                        \
@@ -485,6 +482,8 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
 
 static void stop_workers(ssd_env *env);
 static void aql_teardown(ssd_env *env);
+static int rollout(ssd_env *env, const int32_t *actions, const uint8_t *order, int32_t action_ring, int32_t num_actions, int32_t n_steps,
+                   int32_t reset_every, int32_t step0, void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream);
 
 int ssd_destroy(ssd_env *env) {
     if (!env) return SSD_E_INVALID;
@@ -497,18 +496,6 @@ int ssd_destroy(ssd_env *env) {
     for (hipStream_t cs : env->chain_streams) (void)hipStreamDestroy(cs);
     for (hipEvent_t ce : env->chain_events) (void)hipEventDestroy(ce);
     if (env->fork_event) (void)hipEventDestroy(env->fork_event);
-    {
-        std::lock_guard<std::mutex> lk(g_pipe_owners.mu);
-        const int d = env->device & 63;
-        if (g_pipe_owners.owner[d] == env) { g_pipe_owners.owner[d] = nullptr; g_pipe_owners.done[d] = nullptr; }
-        if (g_pipe_owners.enqueuing[d] == env) g_pipe_owners.enqueuing[d] = nullptr;
-    }
-    if (env->pipe_done) (void)hipEventDestroy(env->pipe_done);
-    for (auto &cp : env->chain_pipe) {
-        if (cp.sb) (void)hipStreamDestroy(cp.sb);
-        if (cp.ev_a) (void)hipEventDestroy(cp.ev_a);
-        if (cp.ev_b) (void)hipEventDestroy(cp.ev_b);
-    }
     delete env;
     return SSD_OK;
 }
@@ -522,7 +509,12 @@ int ssd_step(ssd_env *env, const int32_t *actions, const uint8_t *order, void *o
              uint32_t flags, void *stream) {
     if (!env) return SSD_E_INVALID;
     if (!actions && env->N > 0) { env->err = "actions is null"; return SSD_E_INVALID; }   // an env without agents has no actions
-    if ((flags & SSD_AUTO_RESET) && (flags & SSD_OBS_F32)) { env->err = "SSD_AUTO_RESET writes uint8 observations"; return SSD_E_INVALID; }
+    if ((flags & SSD_AUTO_RESET) && (flags & SSD_OBS_F32)) { env->err = "an auto-reset step writes uint8 observations"; return SSD_E_INVALID; }
+    if (flags & SSD_STEP_CHAINS) {
+        // the step as a one-step ssd_rollout_actions call: env ranges stepped concurrently through the library's own queues
+        if ((flags & (SSD_HOST_PTRS | SSD_AUTO_RESET)) || order) { env->err = "a step through the rollout chains takes device pointers, index action order and no auto-reset"; return SSD_E_INVALID; }
+        return rollout(env, actions, nullptr, 1, 0, 1, 0, 0, obs, rew, done, 1, flags & SSD_OBS_F32, stream);
+    }
     return run(env, (flags & SSD_AUTO_RESET) ? ssd::kModeStepAuto : ssd::kModeStep, actions, order, nullptr, 0, nullptr, obs, rew, done, 1,
                flags, stream);
 }
@@ -532,32 +524,17 @@ int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, voi
     if (!env) return SSD_E_INVALID;
     const int na = env->game == SSD_GAME_HARVEST ? 8 : 9;
     if (num_actions < 1 || num_actions > na) { env->err = "num_actions outside the game's Discrete(n)"; return SSD_E_INVALID; }
-    if ((flags & SSD_AUTO_RESET) && (flags & SSD_OBS_F32)) { env->err = "SSD_AUTO_RESET writes uint8 observations"; return SSD_E_INVALID; }
+    if ((flags & SSD_AUTO_RESET) && (flags & SSD_OBS_F32)) { env->err = "an auto-reset step writes uint8 observations"; return SSD_E_INVALID; }
     return run(env, (flags & SSD_AUTO_RESET) ? ssd::kModeStepAuto : ssd::kModeStep, nullptr, nullptr, nullptr, num_actions, actions_out, obs,
                rew, done, 1, flags, stream);
 }
 
-// (calling thread, before the chains' launches start) what chain c needs to pipeline its launches
-static int ensure_chain_pipe(ssd_env *env, int c) {
-    if (!env->pipe_flags) { int rc = dev_alloc(env, &env->pipe_flags, (size_t)env->E); if (rc) return rc; }
-    if (!env->wave_slots) {
-        int cus = 0;
-        SSD_HIP(env, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, env->device));
-        env->wave_slots = cus * 32;
-    }
-    auto &cp = env->chain_pipe[c];
-    if (cp.sb) return SSD_OK;
-    SSD_HIP(env, hipStreamCreateWithFlags(&cp.sb, hipStreamNonBlocking));
-    SSD_HIP(env, hipEventCreateWithFlags(&cp.ev_a, hipEventDisableTiming));
-    SSD_HIP(env, hipEventCreateWithFlags(&cp.ev_b, hipEventDisableTiming));
-    return SSD_OK;
-}
-
-// The launches of step k of a plain (neither fused nor pipelined) chain: a full reset when one is due, then the step.
+// The launches of step k of a plain (not fused) chain: a full reset when one is due, then the step.
 struct ChainCursor {
     Params p;
     hipStream_t s;
     uint8_t *obs; int32_t *rew; uint8_t *done;
+    const int32_t *actions; const uint8_t *order; int32_t action_ring;
     size_t en, ob;
     int32_t num_actions, reset_every, step0, ring;
 };
@@ -568,19 +545,28 @@ static ChainCursor chain_cursor(const ssd_env *env, const ChainJob &j) {
     c.p.obs_f32 = f32 ? 1 : 0;
     c.p.e_begin = j.e_begin; c.p.E = j.e_end;
     c.s = j.s; c.obs = j.obs; c.rew = j.rew; c.done = j.done;
+    c.actions = j.actions; c.order = j.order; c.action_ring = j.action_ring;
     c.en = (size_t)env->E * env->N; c.ob = obs_bytes(env, f32);
     c.num_actions = j.num_actions; c.reset_every = j.reset_every; c.step0 = j.step0; c.ring = j.ring;
     return c;
+}
+// the step launch's action source: the caller's slot of the action ring, or the device's own draw
+static inline void cursor_actions(ChainCursor &c, Params &p, size_t step_index) {
+    if (c.actions) {
+        const size_t at = (step_index % (size_t)c.action_ring) * c.en;
+        p.actions = c.actions + at; p.order = c.order ? c.order + at : nullptr; p.num_actions_random = 0;
+    } else { p.actions = nullptr; p.order = nullptr; p.num_actions_random = c.num_actions; }
 }
 static inline void chain_launch_step(const ssd_env *env, ChainCursor &c, int k) {
     Params &p = c.p;
     const size_t slot = (size_t)((c.step0 + k) % c.ring);
     p.obs = c.obs ? c.obs + slot * c.ob : nullptr;
     if (c.reset_every > 0 && (c.step0 + k) % c.reset_every == 0) {
-        p.mode = ssd::kModeReset; p.rotate = 0; p.num_actions_random = 0; p.rew = nullptr; p.done = nullptr;
+        p.mode = ssd::kModeReset; p.rotate = 0; p.num_actions_random = 0; p.actions = nullptr; p.order = nullptr; p.rew = nullptr; p.done = nullptr;
         ssd::launch(p, env->game, c.s);
     }
-    p.mode = ssd::kModeStep; p.rotate = 1; p.num_actions_random = c.num_actions;
+    p.mode = ssd::kModeStep; p.rotate = 1;
+    cursor_actions(c, p, (size_t)(c.step0 + k));
     p.rew = c.rew ? c.rew + slot * c.en : nullptr; p.done = c.done ? c.done + slot * c.en : nullptr;
     ssd::launch(p, env->game, c.s);
 }
@@ -588,7 +574,7 @@ static inline void chain_launch_step(const ssd_env *env, ChainCursor &c, int k) 
 // One chain of a rollout: the launches of steps [0, n_steps) for envs [e_begin, e_end), enqueued on j.s by the calling thread
 // (which is on the handle's device).
 static int rollout_chain(ssd_env *env, const ChainJob &j) {
-    const int32_t n_steps = j.n_steps, reset_every = j.reset_every, step0 = j.step0, ring = j.ring;
+    const int32_t n_steps = j.n_steps;
     hipStream_t s = j.s;
     if (j.flags & SSD_ROLLOUT_FUSED) {
         // ONE launch for the whole chain: the kernel keeps each env in LDS / registers across its n_steps steps
@@ -596,53 +582,12 @@ static int rollout_chain(ssd_env *env, const ChainJob &j) {
         Params p = env->p;
         p.obs_f32 = 0;
         p.e_begin = j.e_begin; p.E = j.e_end;
-        p.mode = ssd::kModeRollout; p.rotate = 1; p.num_actions_random = j.num_actions;
-        p.n_steps = n_steps; p.reset_every = reset_every; p.step0 = step0; p.ring = ring;
+        p.mode = ssd::kModeRollout; p.rotate = 1;
+        p.num_actions_random = j.actions ? 0 : j.num_actions;
+        p.actions = j.actions; p.order = j.actions ? j.order : nullptr; p.action_ring = j.actions ? j.action_ring : 0;
+        p.n_steps = n_steps; p.reset_every = j.reset_every; p.step0 = j.step0; p.ring = j.ring;
         p.obs = j.obs; p.rew = j.rew; p.done = j.done;
         ssd::launch(p, env->game, s);
-        return hipGetLastError() == hipSuccess ? SSD_OK : SSD_E_DEVICE;
-    }
-    if (j.pipelined) {
-        // Step launches alternate between the chain's stream and a second one, so two consecutive steps may be in flight at
-        // once; what orders them is the per-env pass counter the kernels wait on and publish (kernel: PIPE).  A reset launch
-        // joins the two streams, runs alone, and the counters start again from zero.
-        const bool f32 = (j.flags & SSD_OBS_F32) != 0;
-        const size_t en = (size_t)env->E * env->N, ob = obs_bytes(env, f32);
-        Params p = env->p;
-        p.obs_f32 = f32 ? 1 : 0;
-        p.e_begin = j.e_begin; p.E = j.e_end;
-        auto &cp = env->chain_pipe[j.chain];
-        hipStream_t st[2] = {s, cp.sb};
-        uint32_t seq = 0;
-        // test knob: the first launch of the call waits for a pass that never ran -- its waves must give up (bounded wait), set
-        // SSD_ST_PIPE_TIMEOUT and let the launch finish
-        static const bool test_stall = [] { const char *v = getenv("SSD_PIPE_TEST_STALL"); return v && atoi(v) != 0; }();
-        bool stall_once = test_stall;
-        auto restart = [&]() -> bool {
-            seq = stall_once ? 1 : 0;
-            stall_once = false;
-            return hipMemsetAsync(env->pipe_flags + j.e_begin, 0, sizeof(uint32_t) * (size_t)(j.e_end - j.e_begin), s) == hipSuccess &&
-                   hipEventRecord(cp.ev_a, s) == hipSuccess && hipStreamWaitEvent(cp.sb, cp.ev_a, 0) == hipSuccess;
-        };
-        auto join = [&]() -> bool { return hipEventRecord(cp.ev_b, cp.sb) == hipSuccess && hipStreamWaitEvent(s, cp.ev_b, 0) == hipSuccess; };
-        if (!restart()) return SSD_E_DEVICE;
-        for (int k = 0; k < n_steps; ++k) {
-            const size_t slot = (size_t)((step0 + k) % ring);
-            p.obs = j.obs ? j.obs + slot * ob : nullptr;
-            if (reset_every > 0 && (step0 + k) % reset_every == 0) {
-                if (!join()) return SSD_E_DEVICE;
-                p.mode = ssd::kModeReset; p.rotate = 0; p.num_actions_random = 0; p.rew = nullptr; p.done = nullptr;
-                p.pipe_flags = nullptr;
-                ssd::launch(p, env->game, s);
-                if (!restart()) return SSD_E_DEVICE;
-            }
-            p.mode = ssd::kModeStep; p.rotate = 1; p.num_actions_random = j.num_actions;
-            p.rew = j.rew ? j.rew + slot * en : nullptr; p.done = j.done ? j.done + slot * en : nullptr;
-            static const uint32_t rotate = [] { const char *v = getenv("SSD_PIPE_ROTATE"); return v ? (uint32_t)atoi(v) : 0u; }();   // test knob
-            p.pipe_flags = env->pipe_flags; p.pipe_seq = ++seq; p.pipe_rotate = rotate;
-            ssd::launch(p, env->game, st[(seq - 1) & 1]);
-        }
-        if (!join()) return SSD_E_DEVICE;
         return hipGetLastError() == hipSuccess ? SSD_OK : SSD_E_DEVICE;
     }
     ChainCursor c = chain_cursor(env, j);
@@ -653,7 +598,7 @@ static int rollout_chain(ssd_env *env, const ChainJob &j) {
 // Body of a chain worker thread (see ChainWorker).
 static void chain_worker_main(ssd_env *env, ChainWorker *w) {
     const bool on_device = hipSetDevice(env->device) == hipSuccess;       // once per thread
-    static const int spin_us = [] { const char *v = getenv("SSD_WORKER_SPIN_US"); return v ? atoi(v) : 200; }();
+    static const int spin_us = SSD_HOOK("SSD_WORKER_SPIN_US", 200);
     for (;;) {
         int st = w->state.load(std::memory_order_acquire);
         if (st != 1 && st != 3) {
@@ -705,10 +650,26 @@ static void stop_workers(ssd_env *env) {
     env->workers.clear();
 }
 
+// Everything the handle ever put into the library's queues has completed when this returns (or a queue has failed).
+// hipDeviceSynchronize() does not cover queues the HIP runtime does not own, so whoever frees memory those packets name --
+// ssd_destroy, an error path that leaves a call's work behind without a stream-side wait -- drains them on the host first.
+static void aql_drain(ssd_env *env) {
+    if (!env->aql) return;
+    AqlState &A = *env->aql;
+    if (!A.ok && !A.nq) return;
+    if (!A.joins || !A.flag_kernarg) return;                        // (nothing was ever enqueued)
+    std::lock_guard<std::mutex> enqueue_lock(ssd::aql::enqueue_mutex(env->device));
+    for (int c = 0; c < A.nq; ++c) {
+        if (!A.q[c] || ssd::aql::queue_failed(A.q[c])) continue;
+        if (ssd::aql::join_and_wait(A.q[c], A.flag_kernarg)) A.joins += 1;
+    }
+}
+
 static void aql_teardown(ssd_env *env) {
     if (!env->aql) return;
     AqlState &A = *env->aql;
-    // (the queues belong to the device's pool and stay; the handle's work in them is done: ssd_destroy synchronised the device)
+    // (the queues belong to the device's pool and stay; the handle's work in them must be over before its memory goes)
+    aql_drain(env);
     for (uint64_t h : A.fork_sig) ssd::aql::signal_destroy(h);
     if (A.join_counter) (void)hipFree(A.join_counter);
     ssd::aql::host_kernarg_free(A.flag_kernarg);
@@ -719,6 +680,31 @@ static void aql_teardown(ssd_env *env) {
     if (A.world_buf[1]) (void)hipFree(A.world_buf[1]);
     if (A.agents_buf[1]) (void)hipFree(A.agents_buf[1]);
     env->aql.reset();
+}
+
+// Is a profiling / tracing tool attached to this process?  Such tools may run kernels ONE AT A TIME (rocprofv3 --pmc does): a
+// kernel that waits for another queue's kernel -- the stream-side wait of the join, the chains' barrier on the fork signal --
+// would then never end.  With a tool attached the rollout calls therefore use host-side waits ("sync mode": the call itself
+// waits for the stream before and for the chains after; no kernel waits for another).  SSD_AQL_SYNC=1 / 0 forces / forbids that.
+// What counts as attached: the variables the ROCm tools are started with, or their libraries already loaded in the process.
+static int tool_attached_now() {
+    static const char *const vars[] = {"ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROF_COUNTER_COLLECTION", "ROCPROFILER_METRICS_PATH",
+                                       "ROCPROF_ATT_LIBRARY_PATH"};
+    for (const char *n : vars) { const char *v = getenv(n); if (v && *v) return 1; }
+    if (const char *pl = getenv("LD_PRELOAD")) { if (std::strstr(pl, "rocprof") || std::strstr(pl, "roctracer") || std::strstr(pl, "omnitrace") || std::strstr(pl, "rocsys")) return 1; }
+    static const char *const libs[] = {"librocprofiler-sdk.so.1", "librocprofiler-sdk.so", "librocprofiler-sdk-tool.so", "librocprofiler64.so.2",
+                                       "librocprofiler64.so.1", "librocprofiler64.so"};
+    for (const char *l : libs)
+        if (void *h = dlopen(l, RTLD_LAZY | RTLD_NOLOAD)) { dlclose(h); return 1; }
+    return 0;
+}
+static bool aql_sync_mode() {
+    static const bool v = [] {
+        const char *e = getenv("SSD_AQL_SYNC");
+        if (e && *e) return atoi(e) != 0;
+        return tool_attached_now() != 0;
+    }();
+    return v;
 }
 
 // Queues for `chains` chains, fork signals: created once.  false: use hipLaunchKernel.
@@ -739,22 +725,24 @@ static bool aql_ready(ssd_env *env, int chains) {
         A.flag_kernarg = ssd::aql::host_kernarg_alloc(env->device, 64);
         if (!A.flag_kernarg) return false;
         std::memcpy(A.flag_kernarg, &A.join_counter, sizeof(void *));
+        {   // first launches of the two helper kernels now (the runtime resolves a kernel on its first launch: ~50 us), not
+            // inside somebody's first short rollout -- and before the pool's first queue is probed (the probe launches one of them)
+            ssd::aql::signal_set(A.fork_sig[0], 1);
+            ssd::launch_signal_kernel(ssd::aql::signal_value_ptr(A.fork_sig[0]), nullptr);
+            ssd::launch_wait_counter_kernel(A.join_counter, 0, nullptr, 0, nullptr, nullptr);
+            if (hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipGetLastError(); return false; }
+        }
         A.q[0] = ssd::aql::pool_queue(env->device, 0);
         if (!A.q[0]) return false;
         A.nq = 1;
-        {   // first launches of the two helper kernels now (the runtime resolves a kernel on its first launch: ~50 us), not
-            // inside somebody's first short rollout
-            ssd::aql::signal_set(A.fork_sig[0], 1);
-            ssd::launch_signal_kernel(ssd::aql::signal_value_ptr(A.fork_sig[0]), nullptr);
-            ssd::launch_wait_counter_kernel(A.join_counter, 0, ssd::aql::abort_flag_dev(env->device), nullptr);
-            if (hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipGetLastError(); return false; }
-        }
         A.ok = true;
     }
-    if (chains > ssd::aql::pool_size()) return false;              // (more chains than the device's pool has queues: HIP streams)
+    if (chains > ssd::aql::pool_size(env->device)) return false;   // (more chains than the device's pool has queues: HIP streams)
     while (A.nq < chains) {
+        // (a queue the probe turns down is not an error of the path: this call goes through HIP streams, later automatic
+        // choices stay within the smaller pool)
         A.q[A.nq] = ssd::aql::pool_queue(env->device, A.nq);
-        if (!A.q[A.nq]) { A.ok = false; return false; }
+        if (!A.q[A.nq]) return false;
         A.nq++;
     }
     for (int c = 0; c < A.nq; ++c) if (ssd::aql::queue_failed(A.q[c])) { A.ok = false; return false; }
@@ -766,7 +754,29 @@ static inline void aql_wait_consumed(ssd::aql::Queue *q, uint64_t idx_plus_1) {
     while (idx_plus_1 && ssd::aql::read_index(q) < idx_plus_1 && !ssd::aql::queue_failed(q)) __builtin_ia32_pause();
 }
 
+// The second state buffers and the render side buffers of split rollouts, once per handle: all six or none.
+static bool aql_split_buffers(ssd_env *env) {
+    AqlState &A = *env->aql;
+    if (A.world_buf[1] && A.agents_buf[1] && A.snap_grid[0] && A.snap_grid[1] && A.beam_list[0] && A.beam_list[1]) return true;
+    const size_t sizes[6] = {(size_t)env->E * env->S, (size_t)env->E * (env->N ? env->N : 1) * 4, (size_t)env->E * env->S, (size_t)env->E * env->S,
+                             (size_t)env->E * 64 * 4, (size_t)env->E * 64 * 4};
+    void *buf[6] = {};
+    for (int i = 0; i < 6; ++i)
+        if (hipMalloc(&buf[i], sizes[i]) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int j = 0; j < i; ++j) (void)hipFree(buf[j]);
+            return false;
+        }
+    A.world_buf[0] = env->p.world; A.agents_buf[0] = env->p.agents;
+    A.world_buf[1] = static_cast<uint8_t *>(buf[0]); A.agents_buf[1] = static_cast<uint32_t *>(buf[1]);
+    A.snap_grid[0] = static_cast<uint8_t *>(buf[2]); A.snap_grid[1] = static_cast<uint8_t *>(buf[3]);
+    A.beam_list[0] = static_cast<uint32_t *>(buf[4]); A.beam_list[1] = static_cast<uint32_t *>(buf[5]);
+    return true;
+}
+
 // The kernel-argument set for this call's parameters: found among the cached ones, or built, uploaded (synchronously) and cached.
+// Argument block `i` of a chain serves the steps whose index is i modulo key.slots = lcm(output ring, action ring): its output slot
+// is i % ring, its action slot i % action_ring.
 static AqlState::Set *aql_set(ssd_env *env, const AqlState::Key &key, int chains, const ChainJob *jobs) {
     AqlState &A = *env->aql;
     A.clock++;
@@ -777,7 +787,7 @@ static AqlState::Set *aql_set(ssd_env *env, const AqlState::Key &key, int chains
     if (st.valid) for (int c = 0; c < 8 && c < A.nq; ++c) aql_wait_consumed(A.q[c], st.last_use[c]);   // nobody reads the old blocks any more
     st.valid = false;
     constexpr int kKinds = AqlState::kKinds;
-    const size_t need = (size_t)chains * key.ring * kKinds * AqlState::kBlock;
+    const size_t need = (size_t)chains * key.slots * kKinds * AqlState::kBlock;
     if (need > st.cap) {
         if (st.dev) (void)hipFree(st.dev);
         st.dev = nullptr; st.cap = 0;
@@ -785,24 +795,12 @@ static AqlState::Set *aql_set(ssd_env *env, const AqlState::Key &key, int chains
         if (hipMalloc(&ptr, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         st.dev = static_cast<uint8_t *>(ptr); st.cap = need;
     }
-    if (key.split && !A.world_buf[1]) {                 // the second state buffers and the render side buffers, once per handle
-        void *w = nullptr, *ag = nullptr;
-        if (hipMalloc(&w, (size_t)env->E * env->S) != hipSuccess || hipMalloc(&ag, (size_t)env->E * (env->N ? env->N : 1) * 4) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        A.world_buf[0] = env->p.world; A.agents_buf[0] = env->p.agents;
-        A.world_buf[1] = static_cast<uint8_t *>(w); A.agents_buf[1] = static_cast<uint32_t *>(ag);
-        for (int i = 0; i < 2; ++i) {
-            void *g = nullptr, *bl = nullptr;
-            if (hipMalloc(&g, (size_t)env->E * env->S) != hipSuccess || hipMalloc(&bl, (size_t)env->E * 64 * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-            A.snap_grid[i] = static_cast<uint8_t *>(g); A.beam_list[i] = static_cast<uint32_t *>(bl);
-        }
-    }
+    if (key.split && !aql_split_buffers(env)) return nullptr;
     std::vector<uint8_t> host(need, 0);
     for (int c = 0; c < chains; ++c) {
         ChainCursor cur = chain_cursor(env, jobs[c]);
-        for (int r = 0; r < key.ring; ++r)
+        for (int i = 0; i < key.slots; ++i) {
+            const int r = i % key.ring;
             for (int kind = 0; kind < kKinds; ++kind) {
                 const int o = kind / AqlState::kKindsPerO, base = kind % AqlState::kKindsPerO;
                 const bool split_kind = base >= AqlState::kRn;
@@ -811,14 +809,15 @@ static AqlState::Set *aql_set(ssd_env *env, const AqlState::Key &key, int chains
                 Params p = cur.p;
                 if (key.split) { p.world = A.world_buf[o]; p.agents = A.agents_buf[o]; }     // the launch reads buffer o
                 p.obs = cur.obs ? cur.obs + (size_t)r * cur.ob : nullptr;
-                // (test knob: launches of orientation 1 use the other geometry)
+                // (test hook: launches of orientation 1 use the other geometry)
                 p.coherent = key.coherent ? ((key.coherent == 2 && o == 1) ? 2u : 1u) : 0u;
                 if (base == AqlState::kR || base == AqlState::kRn) {
-                    p.mode = ssd::kModeReset; p.rotate = 0; p.num_actions_random = 0; p.rew = nullptr; p.done = nullptr;
+                    p.mode = ssd::kModeReset; p.rotate = 0; p.num_actions_random = 0; p.actions = nullptr; p.order = nullptr; p.rew = nullptr; p.done = nullptr;
                     // (every reset of a rollout is followed by a step that writes the same observation slot)
                     if (base == AqlState::kRn) p.obs = nullptr;
                 } else {
-                    p.mode = ssd::kModeStep; p.rotate = 1; p.num_actions_random = cur.num_actions;
+                    p.mode = ssd::kModeStep; p.rotate = 1;
+                    cursor_actions(cur, p, (size_t)i);
                     p.rew = cur.rew ? cur.rew + (size_t)r * cur.en : nullptr; p.done = cur.done ? cur.done + (size_t)r * cur.en : nullptr;
                     if (base >= AqlState::kA) {
                         // env waves: read buffer o, write buffer 1 - o, leave their beam marks in list o.  Renderer workgroups of
@@ -840,12 +839,13 @@ static AqlState::Set *aql_set(ssd_env *env, const AqlState::Key &key, int chains
                 ssd::Launch L;
                 if (!ssd::select(p, env->game, &L)) return nullptr;
                 AqlState::Geo &g = st.geo[c][kind];
-                if (r == 0) {
+                if (i == 0) {
                     if (!ssd::aql::lookup(env->device, L.fn, &g.k) || g.k.kernarg_size > AqlState::kBlock || g.k.kernarg_size < sizeof(ssd::KernArgs)) return nullptr;
                     g.grid_x = L.grid_x; g.block_x = L.block_x; g.lds = L.lds;
                 }
-                std::memcpy(host.data() + (((size_t)c * key.ring + r) * kKinds + kind) * AqlState::kBlock, &L.args, sizeof(ssd::KernArgs));
+                std::memcpy(host.data() + (((size_t)c * key.slots + i) * kKinds + kind) * AqlState::kBlock, &L.args, sizeof(ssd::KernArgs));
             }
+        }
     }
     if (hipMemcpy(st.dev, host.data(), need, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     st.key = key; st.valid = true; st.stamp = A.clock;
@@ -853,8 +853,10 @@ static AqlState::Set *aql_set(ssd_env *env, const AqlState::Key &key, int chains
     return &st;
 }
 
-// ssd_rollout_random through the library's own queues.  Returns SSD_OK, an error, or 1 = "not taken" (the caller then issues
-// the same launches through hipLaunchKernel).
+static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+
+// A rollout through the library's own queues.  Returns SSD_OK, an error, or 1 = "not taken" (the caller then issues the same
+// launches through hipLaunchKernel).
 static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream_t s) {
     if (!aql_ready(env, chains)) return 1;
     AqlState &A = *env->aql;
@@ -862,19 +864,27 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     AqlState::Key key;
     key.obs = j0.obs; key.rew = j0.rew; key.done = j0.done; key.ring = j0.ring; key.f32 = (j0.flags & SSD_OBS_F32) ? 1 : 0;
     key.num_actions = j0.num_actions; key.chains = chains; key.horizon = env->p.horizon;
+    key.actions = j0.actions; key.order = j0.actions ? j0.order : nullptr; key.action_ring = j0.actions ? j0.action_ring : 0;
+    {   // one argument block per chain, kind and residue of the step index modulo lcm(output ring, action ring)
+        const long long ar = key.action_ring > 0 ? key.action_ring : 1;
+        const long long l = (long long)key.ring / gcd_i(key.ring, (int)ar) * ar;
+        if (l * chains > 2048) return 1;                            // (12 x 512 B per chain and block index)
+        key.slots = (int32_t)l;
+    }
     key.stamps = env->p.stamps; key.dbg_skip = env->p.dbg_skip;
     // Coherent chains: with a map-specific uint8 kernel (and its write-through observation stores: up to 16 384 envs per launch)
-    // state and outputs move with agent-scope accesses only, so the step packets need no release fence (ssd_kernels.hip, PIPE = 2).
-    // SSD_AQL_COHERENT=0 keeps the plain kernels with agent-scope acquire + release on every packet; SSD_AQL_ALTERNATE=1 (test)
-    // makes every other launch use half the envs per workgroup -- an env then changes workgroup, and with it XCD and L2, from
-    // one launch to the next that touches it.
-    static const int env_coh = [] { const char *v = getenv("SSD_AQL_COHERENT"); return v ? atoi(v) : 1; }();
-    static const bool alternate = [] { const char *v = getenv("SSD_AQL_ALTERNATE"); return v && atoi(v) != 0; }();
+    // state and outputs move with agent-scope accesses only, so the step packets need no release fence (ssd_kernels.hip, COH).
+    // SSD_AQL_COHERENT=0 keeps the plain kernels with agent-scope acquire + release on every packet; SSD_AQL_ALTERNATE=1 (test
+    // hook) makes every other launch use half the envs per workgroup -- an env then changes workgroup, and with it XCD and L2,
+    // from one launch to the next that touches it.
+    static const int env_coh = SSD_KNOB("SSD_AQL_COHERENT", 1);
+    static const bool alternate = SSD_HOOK("SSD_AQL_ALTERNATE", 0) != 0;
     // (measured, us per step: 2048 envs per launch 5.5 split / 5.9 coherent / 6.2 plain; 2730: 9.7 / 8.6 / 8.7; 5461: 19.1 / 15.2 /
     // 14.3 -- once a launch is several rounds of waves the kernel is bandwidth-bound, and re-reading state from an L2 that still
     // holds it beats fetching it from memory: coherent chains up to 4096 envs per launch, split ones up to 2304)
     const int per_launch = (env->E + chains - 1) / chains;
-    const bool coherent = env_coh != 0 && !key.f32 && ssd::fast_profile(env->p, env->game) > 0 && per_launch <= 4096;
+    // (an explicit action order takes the general kernels: no coherent variant)
+    const bool coherent = env_coh != 0 && !key.f32 && !key.order && ssd::fast_profile(env->p, env->game) > 0 && per_launch <= 4096;
     key.coherent = coherent ? (alternate ? 2 : 1) : 0;
     // Split rollouts (coherent chains with observations, 4 steps or more): the wave that steps an env does not render its
     // observations; the NEXT step's launch carries a second set of workgroups that render them while that step is being computed,
@@ -885,30 +895,30 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     // launches per step in one queue -- step, then an observe launch beside the next step -- do not work: kernels of one queue run
     // one after the other on this device even without the barrier bit: two chains' launches in ONE queue take 10.6 us per step, in
     // two queues 5.8.)  SSD_AQL_SPLIT=0 turns it off.
-    static const int env_split = [] { const char *v = getenv("SSD_AQL_SPLIT"); return v ? atoi(v) : 1; }();
+    static const int env_split = SSD_KNOB("SSD_AQL_SPLIT", 1);
     key.split = (coherent && env_split != 0 && j0.obs != nullptr && per_launch <= 2304) ? 1 : 0;   // (the argument set holds both forms' launches)
     const bool split = key.split && j0.n_steps >= 4;
     // (a split set holds its launches for both orientations of the state pair; any other set names the buffer that is current now)
     key.world = key.split ? nullptr : env->p.world;
-    env->last_path |= SSD_PATH_AQL | (coherent ? SSD_PATH_COHERENT : 0) | (split ? SSD_PATH_SPLIT : 0);
-    if ((size_t)chains * j0.ring > 2048) return 1;                     // (argument blocks: 10 x 512 B per chain and slot)
     AqlState::Set *st = aql_set(env, key, chains, jobs);
     if (!st) return 1;
+    // (only now is the call certain to take this path: ssd_rollout_path() must not name a path the launches did not take)
+    env->last_path |= SSD_PATH_AQL | (coherent ? SSD_PATH_COHERENT : 0) | (split ? SSD_PATH_SPLIT : 0);
     if (j0.n_steps == 0) return SSD_OK;
     // (the queues are the device's, shared with the other handles on it: one call writes packets at a time)
     std::lock_guard<std::mutex> enqueue_lock(ssd::aql::enqueue_mutex(env->device));
     // FORK: the chains wait (barrier-AND) for a signal that a one-wave kernel on the caller's stream zeroes -- unless the
     // stream has nothing pending, in which case there is nothing to wait for and the first step can start at once
-    static const bool always_fork = [] { const char *v = getenv("SSD_AQL_ALWAYS_FORK"); return v && atoi(v) != 0; }();
-    // SSD_AQL_SYNC=1: the call itself waits -- for the stream before, for the chains after -- and no kernel waits for another
-    // queue's kernel.  For tools that serialise kernels (rocprofv3 --pmc): there the waiting kernel of the join would spin forever.
-    static const bool sync_mode = [] { const char *v = getenv("SSD_AQL_SYNC"); return v && atoi(v) != 0; }();
-    if (sync_mode) SSD_HIP(env, hipStreamSynchronize(s));
+    static const bool always_fork = SSD_HOOK("SSD_AQL_ALWAYS_FORK", 0) != 0;
+    // Sync mode: the call itself waits -- for the stream before, for the chains after -- and no kernel waits for another queue's
+    // kernel.  Chosen automatically when a profiling tool is attached (aql_sync_mode), or with SSD_AQL_SYNC=1.
+    const bool sync_mode = aql_sync_mode();
+    if (sync_mode) { SSD_HIP(env, hipStreamSynchronize(s)); env->last_path |= SSD_PATH_SYNC; }
     bool stream_idle = sync_mode || (!always_fork && hipStreamQuery(s) == hipSuccess);
     if (!stream_idle && !always_fork) {
         // a marker or an event record just ahead of the call drains within microseconds: look again for a moment before paying
         // for a fork (a kernel launch on the stream + a barrier packet that polls its signal: ~20 us until the first step starts)
-        static const int spin_us = [] { const char *v = getenv("SSD_AQL_FORK_SPIN_US"); return v ? atoi(v) : 8; }();
+        static const int spin_us = SSD_HOOK("SSD_AQL_FORK_SPIN_US", 8);
         const auto t0 = std::chrono::steady_clock::now();
         while (!stream_idle && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us))
             stream_idle = hipStreamQuery(s) == hipSuccess;
@@ -920,62 +930,68 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
         for (int c = 0; c < A.nq; ++c) { aql_wait_consumed(A.q[c], A.fork_used[slot][c]); A.fork_used[slot][c] = 0; }
         ssd::aql::signal_set(A.fork_sig[slot], 1);
         ssd::launch_signal_kernel(ssd::aql::signal_value_ptr(A.fork_sig[slot]), s);
+        // (nothing is in the library's queues yet: an error here leaves nothing behind)
         if (hipGetLastError() != hipSuccess) { env->err = "fork kernel launch failed"; return SSD_E_DEVICE; }
         for (int c = 0; c < chains; ++c) {
             ssd::aql::barrier_and(A.q[c], A.fork_sig[slot]);
             A.fork_used[slot][c] = ssd::aql::write_index(A.q[c]);     // (= index of the barrier packet + 1)
         }
+        env->last_path |= SSD_PATH_FORKED;
     }
-    // fence scopes of the step packets (hsa_fence_scope_t: 0 none, 1 agent, 2 system); the SSD_AQL_* variables are tuning
-    // knobs -- for the plain kernels anything weaker than agent / agent gives up the visibility a HIP stream provides
-    static const int env_acq = [] { const char *v = getenv("SSD_AQL_ACQ"); return v ? atoi(v) : -1; }();
-    static const int env_rel = [] { const char *v = getenv("SSD_AQL_REL"); return v ? atoi(v) : -1; }();
+    // fence scopes of the step packets (hsa_fence_scope_t: 0 none, 1 agent, 2 system).  Test-hook build only: SSD_AQL_ACQ /
+    // SSD_AQL_REL override them -- for the plain kernels anything weaker than agent / agent gives up the visibility a HIP stream
+    // provides, which is why the product does not read them.
+    static const int env_acq = SSD_HOOK("SSD_AQL_ACQ", -1);
+    static const int env_rel = SSD_HOOK("SSD_AQL_REL", -1);
     // Coherent chains: only the first packet of the call acquires (what the caller's stream did before -- a set_state, another
     // kernel -- may sit in caches); between the chain's own launches nothing is read through a cache that could be stale
     // (-0.14 us per step); the renderer workgroups of a split rollout read state and beam lists with agent-scope loads as well.
     const int kAcq = env_acq >= 0 ? env_acq : (coherent ? 0 : 1), kRel = env_rel >= 0 ? env_rel : (coherent ? 0 : 1);
-    const int32_t ring = j0.ring, reset_every = j0.reset_every, step0 = j0.step0;
+    const int32_t reset_every = j0.reset_every, step0 = j0.step0, slots = key.slots;
     constexpr int kKinds = AqlState::kKinds;
-    auto put = [&](int c, size_t r, int kind, bool barrier, int acq, int rel) {
+    auto put = [&](int c, size_t i, int kind, bool barrier, int acq, int rel) {
         const AqlState::Geo &g = st->geo[c][kind];
-        ssd::aql::dispatch(A.q[c], g.k, g.grid_x, g.block_x, g.lds, st->dev + (((size_t)c * ring + r) * kKinds + kind) * AqlState::kBlock,
+        ssd::aql::dispatch(A.q[c], g.k, g.grid_x, g.block_x, g.lds, st->dev + (((size_t)c * slots + i) * kKinds + kind) * AqlState::kBlock,
                            barrier, acq, rel);
     };
     // orientation: which buffer of the pair holds the current state (always 0 until the first split rollout of the handle)
     int o = (A.world_buf[1] && env->p.world == A.world_buf[1]) ? 1 : 0;
     const int KO = AqlState::kKindsPerO;
     bool pending = false;                                 // a step's observations are still to be rendered (split rollouts)
-    size_t r_prev = 0;
+    size_t i_prev = 0;
     for (int k = 0; k < j0.n_steps; ++k) {
-        const size_t r = (size_t)((step0 + k) % ring);
+        const size_t i = (size_t)((step0 + k) % slots);   // argument block of this step (output slot i % ring, action slot i % action_ring)
         const bool reset = reset_every > 0 && (step0 + k) % reset_every == 0;
         for (int c = 0; c < chains; ++c) {
             const int acq = k == 0 ? 1 : kAcq;                                 // (the call's first launch of the chain)
             if (reset) {
                 // (a reset works in place: the step before it must have been rendered from that buffer first)
-                if (split && pending) put(c, r_prev, o * KO + AqlState::kB, true, kAcq, kRel);
-                put(c, r, o * KO + (split ? AqlState::kRn : AqlState::kR), true, acq, kRel);
+                if (split && pending) put(c, i_prev, o * KO + AqlState::kB, true, kAcq, kRel);
+                put(c, i, o * KO + (split ? AqlState::kRn : AqlState::kR), true, acq, kRel);
             }
             const int base = !split ? AqlState::kS : (pending && !reset) ? AqlState::kAB : AqlState::kA;
-            put(c, r, o * KO + base, true, reset ? kAcq : acq, kRel);
-            if (split && k == j0.n_steps - 1) put(c, r, (1 - o) * KO + AqlState::kB, true, kAcq, kRel);   // (renders the buffer this step wrote)
+            put(c, i, o * KO + base, true, reset ? kAcq : acq, kRel);
+            if (split && k == j0.n_steps - 1) put(c, i, (1 - o) * KO + AqlState::kB, true, kAcq, kRel);   // (renders the buffer this step wrote)
             // (tried: the call's last step rendering itself, its renderer waves in the env's own workgroup behind a barrier -- with
             // a one-slot ring both write the same bytes -- instead of the renderer-only launch: 6.60 against 6.62 us per step of
             // a 20-step call, no gain)
             ssd::aql::ring(A.q[c]);
         }
-        if (split) { o = 1 - o; pending = true; r_prev = r; }
+        if (split) { o = 1 - o; pending = true; i_prev = i; }
     }
     if (split) {                                          // the current state now sits in buffer o
         env->p.world = A.world_buf[o]; env->p.agents = A.agents_buf[o];
     }
     // JOIN: every chain ends by bumping the join counter; a one-wave kernel on the caller's stream sleeps until all have
-    if (sync_mode) {
+    auto host_join = [&]() -> bool {                      // the synchronous form: the HOST waits for every chain
         bool ok = true;
         for (int c = 0; c < chains; ++c) ssd::aql::ring(A.q[c]);
         for (int c = 0; c < chains; ++c) { ok = ssd::aql::join_and_wait(A.q[c], A.flag_kernarg) && ok; st->last_use[c] = ssd::aql::write_index(A.q[c]); }
         A.joins += (unsigned long long)chains;
-        if (!ok) { env->err = "the HSA runtime reported an error on a dispatch queue"; A.ok = false; return SSD_E_DEVICE; }
+        return ok;
+    };
+    if (sync_mode) {
+        if (!host_join()) { env->err = "the HSA runtime reported an error on a dispatch queue"; A.ok = false; return SSD_E_DEVICE; }
         return SSD_OK;
     }
     for (int c = 0; c < chains; ++c) {
@@ -983,18 +999,30 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
         st->last_use[c] = ssd::aql::write_index(A.q[c]);
     }
     A.joins += (unsigned long long)chains;
-    ssd::launch_wait_counter_kernel(A.join_counter, A.joins, ssd::aql::abort_flag_dev(env->device), s);
-    if (hipGetLastError() != hipSuccess) { env->err = "join kernel launch failed"; A.ok = false; return SSD_E_DEVICE; }
+    // (the stream-side wait is bounded: seconds beyond any healthy call -- ssd_kernels.hip, ssd_wait_counter_kernel)
+    unsigned long long timeout_ticks = (unsigned long long)((2.0 + 0.002 * (double)j0.n_steps) * 1e8);
+    // (test hooks: wait for a count that never comes / with a short bound -- tests/test_hip_fullsize.py, test_join_wait_is_bounded)
+    static const int test_lost = SSD_HOOK("SSD_AQL_TEST_LOST_JOIN", 0), test_timeout_ms = SSD_HOOK("SSD_AQL_TEST_TIMEOUT_MS", 0);
+    if (test_timeout_ms > 0) timeout_ticks = (unsigned long long)test_timeout_ms * 100000ull;
+    (void)hipGetLastError();                              // (an earlier, unrelated sticky error of the caller's must not be read as ours)
+    ssd::launch_wait_counter_kernel(A.join_counter, A.joins + (test_lost ? 1000000ull : 0ull), ssd::aql::abort_flag_dev(env->device), timeout_ticks,
+                                    env->p.status, s);
+    if (hipGetLastError() != hipSuccess) {
+        // the chains' packets are out and nothing on the stream waits for them: wait here, so that the call's work is over (and
+        // its results in place) when the error is returned -- nobody frees or reuses memory under running kernels
+        bool ok = true;
+        for (int c = 0; c < chains; ++c) ok = ssd::aql::join_and_wait(A.q[c], A.flag_kernarg) && ok;
+        A.joins += (unsigned long long)chains;
+        env->err = "join kernel launch failed (the call's work was waited for on the host)"; A.ok = false;
+        return SSD_E_DEVICE;
+    }
     for (int c = 0; c < chains; ++c) if (ssd::aql::queue_failed(A.q[c])) { env->err = "the HSA runtime reported an error on a dispatch queue"; A.ok = false; return SSD_E_DEVICE; }
     return SSD_OK;
 }
 
-int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32_t reset_every, int32_t step0,
-                       void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream) {
-    if (!env || n_steps < 0 || reset_every < 0 || step0 < 0 || ring < 1) return SSD_E_INVALID;
-    if (flags & SSD_HOST_PTRS) { env->err = "ssd_rollout_random takes device pointers"; return SSD_E_INVALID; }
-    const int na = env->game == SSD_GAME_HARVEST ? 8 : 9;
-    if (num_actions < 1 || num_actions > na) { env->err = "num_actions outside the game's Discrete(n)"; return SSD_E_INVALID; }
+// ssd_rollout_random and ssd_rollout_actions: the same launches, the actions drawn on the device or read from the caller's ring.
+static int rollout(ssd_env *env, const int32_t *actions, const uint8_t *order, int32_t action_ring, int32_t num_actions, int32_t n_steps,
+                   int32_t reset_every, int32_t step0, void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream) {
     if (obs && (reinterpret_cast<uintptr_t>(obs) & 3u)) { env->err = "obs must be 4-byte aligned"; return SSD_E_INVALID; }
     if ((flags & SSD_ROLLOUT_FUSED) && (flags & SSD_OBS_F32)) { env->err = "the fused rollout kernel writes uint8 observations"; return SSD_E_INVALID; }
     {
@@ -1004,81 +1032,39 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
     hipStream_t s = static_cast<hipStream_t>(stream);
     env->last_stream = s; env->last_stream_set = true;
     uint8_t *o = static_cast<uint8_t *>(obs);
-    // Pipelined launches (SSD_ROLLOUT_PIPELINED; SSD_ROLLOUT_PIPELINE=1 / 0 in the environment forces / forbids them): only the
-    // known maps' uint8 kernels have the variant, consecutive steps must not share an output slot, and the launches that can
-    // be in flight together must fit on the device with room to spare -- a wave that waits for its env's previous pass must
-    // never keep that pass from getting a slot.
-    static const int env_pipe = [] { const char *v = getenv("SSD_ROLLOUT_PIPELINE"); return v ? (atoi(v) != 0 ? 1 : 0) : -1; }();
-    bool pipelined = (env_pipe >= 0 ? env_pipe == 1 : (flags & SSD_ROLLOUT_PIPELINED) != 0) &&
-                     !(flags & (SSD_ROLLOUT_FUSED | SSD_OBS_F32)) && ring >= 2 && n_steps >= 2 &&
-                     ssd::fast_profile(env->p, env->game) > 0;
-    if (pipelined) {
-        int rc = ensure_chain_pipe(env, 0);
-        if (rc) return rc;
-        // resident waves the device can hold of this kernel: 32 per CU, or what 160 KB of LDS per CU allow.  Two launches of a
-        // chain can be in flight at once: they must fit with a fifth of the device to spare (other streams' kernels).
-        Params q = env->p;
-        q.mode = ssd::kModeStep;
-        const size_t lds_wave = ssd::lds_bytes(q, 1, false);
-        const int per_cu = (int)((size_t)160 * 1024 / (lds_wave ? lds_wave : 1));
-        const long long cap = (long long)(env->wave_slots / 32) * (per_cu < 32 ? per_cu : 32);
-        static const bool tight = [] { const char *v = getenv("SSD_PIPELINE_TIGHT"); return v && atoi(v) != 0; }();   // tuning: no margin
-        if (2LL * env->E * (tight ? 4 : 5) > cap * 4) pipelined = false;
-    }
-    // Envs are independent, so a rollout is as many independent launch chains as we like.  Two chains on two streams keep the
+    // Envs are independent, so a rollout is as many independent launch chains as we like.  Two chains in two queues keep the
     // GPU busy while the other chain's kernel drains and the next one is dispatched -- the ~2 us per launch that a single
     // chain of dependent kernels cannot hide.  SSD_ROLLOUT_CHAINS overrides.
-    static const int forced = [] { const char *v = getenv("SSD_ROLLOUT_CHAINS"); return v ? atoi(v) : 0; }();
+    static const int forced = SSD_KNOB("SSD_ROLLOUT_CHAINS", 0);
     int chains = env->rollout_chains > 0 ? env->rollout_chains : forced > 0 ? forced : (env->E < 2048 ? 1 : (env->E >= 6144 && env->E <= 24576) ? 3 : 2);   // measured: profiles/r01_sweep_envs.txt
     if ((flags & SSD_ROLLOUT_FUSED) && env->rollout_chains <= 0 && forced <= 0) chains = 1;   // one launch already covers the whole rollout
     // (an automatic choice stays within the library's own dispatch queues: ssd_aql.hip, pool_size())
-    if (env->rollout_chains <= 0 && forced <= 0 && chains > ssd::aql::pool_size()) chains = ssd::aql::pool_size();
-    // From here on every exit path must give the device's pipelining slot back: the guard does.
-    struct PipeGuard {
-        ssd_env *env; bool held = false; hipStream_t s;
-        ~PipeGuard() {
-            if (!held) return;
-            if (env->pipe_done) (void)hipEventRecord(env->pipe_done, s);
-            std::lock_guard<std::mutex> lk(g_pipe_owners.mu);
-            if (g_pipe_owners.enqueuing[env->device & 63] == env) g_pipe_owners.enqueuing[env->device & 63] = nullptr;
-        }
-    } guard{env, false, s};
-    if (pipelined) {
-        if (!env->pipe_done) SSD_HIP(env, hipEventCreateWithFlags(&env->pipe_done, hipEventDisableTiming));
-        std::lock_guard<std::mutex> lk(g_pipe_owners.mu);
-        const int d = env->device & 63;
-        if ((g_pipe_owners.enqueuing[d] && g_pipe_owners.enqueuing[d] != env) ||
-            (g_pipe_owners.owner[d] && g_pipe_owners.owner[d] != env && hipEventQuery(g_pipe_owners.done[d]) == hipErrorNotReady))
-            pipelined = false;                                      // another handle's pipelined rollout is being enqueued or still in flight
-        else {
-            g_pipe_owners.owner[d] = g_pipe_owners.enqueuing[d] = env, g_pipe_owners.done[d] = env->pipe_done;
-            guard.held = true;
-        }
-    }
-    if (pipelined && env->rollout_chains <= 0 && forced <= 0) chains = 1;   // a pipelined chain overlaps its own launches (measured: 1 beats 2)
+    if (env->rollout_chains <= 0 && forced <= 0 && chains > ssd::aql::pool_size(env->device)) chains = ssd::aql::pool_size(env->device);
     if (chains > 8) chains = 8;
     if (chains > env->E) chains = env->E;
     if (chains < 1) chains = 1;
-    env->last_path = (chains << 8) | ((flags & SSD_ROLLOUT_FUSED) ? SSD_PATH_FUSED : 0) | (pipelined ? SSD_PATH_PIPELINED : 0);
-    for (int c = 1; pipelined && c < chains; ++c) { int rc = ensure_chain_pipe(env, c); if (rc) return rc; }
+    env->last_path = (chains << 8) | ((flags & SSD_ROLLOUT_FUSED) ? SSD_PATH_FUSED : 0);
     auto range = [&](int c) { return (int)(((long long)env->E * c) / chains); };
     auto job_of = [&](int c, hipStream_t cs) {
         ChainJob j;
-        j.pipelined = pipelined; j.chain = c; j.e_begin = range(c); j.e_end = range(c + 1);
+        j.chain = c; j.e_begin = range(c); j.e_end = range(c + 1);
         j.num_actions = num_actions; j.n_steps = n_steps; j.reset_every = reset_every; j.step0 = step0; j.ring = ring;
+        j.actions = actions; j.order = order; j.action_ring = action_ring;
         j.obs = o; j.rew = rew; j.done = done; j.flags = flags; j.s = cs;
         return j;
     };
-    if (!pipelined && !(flags & SSD_ROLLOUT_FUSED)) {
+    if (!(flags & SSD_ROLLOUT_FUSED)) {
         // the library's own dispatch path: the same launches as below, written as AQL packets into its own queues
         ChainJob jobs[8];
         for (int c = 0; c < chains; ++c) jobs[c] = job_of(c, s);
         const int rc = rollout_aql(env, chains, jobs, s);
+        env->last_path |= ssd::aql::pool_report(env->device);
         if (rc <= 0) return rc;
+        env->last_path &= ~(SSD_PATH_AQL | SSD_PATH_COHERENT | SSD_PATH_SPLIT | SSD_PATH_SYNC | SSD_PATH_FORKED);
     }
     if (chains <= 1) {
         int rc = rollout_chain(env, job_of(0, s));
-        if (rc) env->err = "kernel launch failed in ssd_rollout_random";
+        if (rc) env->err = "kernel launch failed in a rollout call";
         return rc;
     }
     while ((int)env->chain_streams.size() < chains - 1) {
@@ -1090,12 +1076,11 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
     if (!env->fork_event) SSD_HIP(env, hipEventCreateWithFlags(&env->fork_event, hipEventDisableTiming));
     // Who enqueues.  The chains' launches either come from this thread, step by step across the chains (no other thread
     // involved: a short call costs its launches and nothing else), or each extra chain from its persistent worker thread
-    // (long calls: two threads enqueue ~10 % faster than one, and pipelined chains have per-chain state machines).
-    // SSD_ROLLOUT_THREADS=0 / 1 forces one or the other.
-    static const int env_threads = [] { const char *v = getenv("SSD_ROLLOUT_THREADS"); return v ? atoi(v) : -1; }();
-    static const int inline_steps = [] { const char *v = getenv("SSD_ROLLOUT_INLINE_STEPS"); return v ? atoi(v) : 256; }();
-    bool threads = pipelined || (!(flags & SSD_ROLLOUT_FUSED) && n_steps > inline_steps);
-    if (env_threads == 0 && !pipelined) threads = false;
+    // (long calls: two threads enqueue ~10 % faster than one).  (Test-hook build: SSD_ROLLOUT_THREADS=0 / 1 forces one or the other.)
+    static const int env_threads = SSD_HOOK("SSD_ROLLOUT_THREADS", -1);
+    static const int inline_steps = SSD_HOOK("SSD_ROLLOUT_INLINE_STEPS", 256);
+    bool threads = !(flags & SSD_ROLLOUT_FUSED) && n_steps > inline_steps;
+    if (env_threads == 0) threads = false;
     if (env_threads == 1) threads = true;
     // fork: the extra chains start after whatever the caller's stream holds so far
     SSD_HIP(env, hipEventRecord(env->fork_event, s));
@@ -1124,9 +1109,28 @@ int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32
         SSD_HIP(env, hipEventRecord(env->chain_events[c - 1], env->chain_streams[c - 1]));
         SSD_HIP(env, hipStreamWaitEvent(s, env->chain_events[c - 1], 0));
     }
-    if (rc_all) env->err = "kernel launch failed in ssd_rollout_random";
+    if (rc_all) env->err = "kernel launch failed in a rollout call";
     return rc_all;
 }
+
+int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32_t reset_every, int32_t step0,
+                       void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream) {
+    if (!env || n_steps < 0 || reset_every < 0 || step0 < 0 || ring < 1) return SSD_E_INVALID;
+    if (flags & SSD_HOST_PTRS) { env->err = "ssd_rollout_random takes device pointers"; return SSD_E_INVALID; }
+    const int na = env->game == SSD_GAME_HARVEST ? 8 : 9;
+    if (num_actions < 1 || num_actions > na) { env->err = "num_actions outside the game's Discrete(n)"; return SSD_E_INVALID; }
+    return rollout(env, nullptr, nullptr, 0, num_actions, n_steps, reset_every, step0, obs, rew, done, ring, flags, stream);
+}
+
+int ssd_rollout_actions(ssd_env *env, const int32_t *actions, const uint8_t *order, int32_t action_ring, int32_t n_steps, int32_t reset_every,
+                        int32_t step0, void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream) {
+    if (!env || n_steps < 0 || reset_every < 0 || step0 < 0 || ring < 1 || action_ring < 1) return SSD_E_INVALID;
+    if (flags & SSD_HOST_PTRS) { env->err = "ssd_rollout_actions takes device pointers"; return SSD_E_INVALID; }
+    if (!actions && env->N > 0) { env->err = "actions is null"; return SSD_E_INVALID; }
+    return rollout(env, actions, order, action_ring, 0, n_steps, reset_every, step0, obs, rew, done, ring, flags, stream);
+}
+
+int ssd_profiler_attached(void) { return tool_attached_now(); }
 
 int ssd_observe(ssd_env *env, void *obs, uint32_t flags, void *stream) {
     if (!env || !obs) return SSD_E_INVALID;
@@ -1255,7 +1259,7 @@ int ssd_set_state(ssd_env *env, const int8_t *world, const int8_t *beam, const i
 
 int ssd_render_frames(ssd_env *env, int32_t e_begin, int32_t count, uint8_t *rgb, uint32_t flags, void *stream) {
     if (!env || !rgb || e_begin < 0 || count < 0 || (int64_t)e_begin + count > env->E) return SSD_E_INVALID;
-    if (flags & ~(uint32_t)SSD_HOST_PTRS) { env->err = "ssd_render_frames: only SSD_HOST_PTRS is meaningful here"; return SSD_E_INVALID; }
+    if (flags & ~(uint32_t)SSD_HOST_PTRS) { env->err = "ssd_render_frames: only the host-pointer flag is meaningful here"; return SSD_E_INVALID; }
     if (count == 0) return SSD_OK;
     SSD_HIP(env, hipSetDevice(env->device));
     const size_t frame = (size_t)env->H * env->W * 3;
@@ -1300,7 +1304,7 @@ int ssd_render_full(ssd_env *env, int32_t e, uint8_t *rgb) {
 int ssd_agent_action_obs(ssd_env *env, const int32_t *actions, const uint8_t *done_mask, int64_t *other_actions, int64_t *visible,
                          uint32_t flags, void *stream) {
     if (!env) return SSD_E_INVALID;
-    if (flags & ~(uint32_t)SSD_HOST_PTRS) { env->err = "ssd_agent_action_obs: only SSD_HOST_PTRS is meaningful here"; return SSD_E_INVALID; }
+    if (flags & ~(uint32_t)SSD_HOST_PTRS) { env->err = "ssd_agent_action_obs: only the host-pointer flag is meaningful here"; return SSD_E_INVALID; }
     const int E = env->E, N = env->N;
     if (N < 2 || (!other_actions && !visible)) return SSD_OK;           // (N - 1 == 0 columns)
     SSD_HIP(env, hipSetDevice(env->device));

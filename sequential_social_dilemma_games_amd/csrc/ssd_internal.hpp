@@ -1,8 +1,21 @@
 // csrc/ssd_internal.hpp -- kernel parameter block shared by ssd_kernels.hip and ssd_capi.hip.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace ssd {
+
+// Environment knobs.  The product library reads only the documented, safe ones (the table in include/ssd.h): SSD_KNOB.
+// Everything else -- fence scopes, forced forks, alternating geometries, tuning overrides -- is a test hook: SSD_HOOK reads the
+// variable only in the test-hook build (make testhooks: -DSSD_TESTHOOKS, libssd_hip_testhooks.so, loaded by the tests that need
+// one) and is the constant default in the product.
+inline int knob_int(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
+#define SSD_KNOB(name, dflt) ::ssd::knob_int(name, dflt)
+#ifdef SSD_TESTHOOKS
+#define SSD_HOOK(name, dflt) ::ssd::knob_int(name, dflt)
+#else
+#define SSD_HOOK(name, dflt) (dflt)
+#endif
 
 constexpr int kWave = 64;          // CDNA wavefront width
 constexpr int kMaxEnvsPerBlock = 16; // one wavefront per env; a workgroup holds 1..16 envs (chosen per launch, see launch())
@@ -61,7 +74,7 @@ struct Params {
     uint32_t thr_h32[4];           // Harvest apple thresholds by min(#neighbour apples, 3): rand < p  <=>  u32 draw < thr
     uint32_t thr_h_always;         // bit n set: threshold n is 2^32 (p >= 1), the compare always succeeds
     // per-call I/O (device pointers; any may be null)
-    const int32_t *actions;        // [E][N]
+    const int32_t *actions;        // [E][N]; a fused rollout with caller-supplied actions: [action_ring][E_total][N], see below
     const uint8_t *order;          // [E][N]
     const uint8_t *mask;           // [E]     reset only
     int32_t *actions_out;          // [E][N]
@@ -70,11 +83,10 @@ struct Params {
     uint8_t *done;                 // [E][N]
     uint32_t dbg_skip;             // diagnostic builds (-DSSD_STAMPS) only: bit mask of phases to skip (tools/variant_times.py)
     unsigned long long *stamps;    // [E][16] s_memtime stamps; diagnostic builds (-DSSD_STAMPS) only, else null
-    // pipelined rollouts: [E] number of the last pass each env has completed in this rollout call, and this launch's number.
-    // A launch with pipe_flags waits, env by env, for pass pipe_seq - 1 instead of relying on stream order (see ssd_capi.hip).
-    uint32_t *pipe_flags;
-    uint32_t pipe_seq;
-    uint32_t coherent;             // the step launch moves state and outputs with agent-scope (sc1) accesses only (kernel: PIPE = 2); set by
+    // kModeRollout with caller-supplied actions (ssd_rollout_actions + SSD_ROLLOUT_FUSED): step k of the call takes its actions
+    // from slot (step0 + k) % action_ring of `actions`; 0: the launch draws its actions (num_actions_random)
+    int32_t action_ring;
+    uint32_t coherent;             // the step launch moves state and outputs with agent-scope (sc1) accesses only (kernel: COH); set by
                                    // the library's own dispatch path for the map-specific uint8 kernels (ssd_aql.hip)
     // split rollouts (bits): 1 = the envs' waves do not render: they write grid and agents to `world_out` / `agents_out` (the other
     // buffer of the pair), this step's beam marks to `beam_list` (and, for the rare step whose marks are not in registers, the
@@ -88,8 +100,6 @@ struct Params {
     uint8_t *snap;                 // [E][S]  overlay of the step (world <- agents <- beams), only after steps that could not list their marks
     const uint8_t *snap_in;        // the previous step's
     uint8_t *obs_b;                // [E][N][V][V][3]  where the renderer workgroups write
-    uint32_t pipe_rotate;          // test knob (SSD_PIPE_ROTATE): shift the env -> workgroup mapping by this many workgroups per launch,
-                                   // so that an env's consecutive steps run on different XCDs (workgroups go round-robin to XCDs)
 };
 
 // The kernarg segment of ssd_env_kernel: its nine leading arguments (repeated Params fields, 56 bytes: preloaded into SGPRs
@@ -122,7 +132,9 @@ bool select(const Params &p, int game, Launch *out);   // resolve a launch witho
 void launch(const Launch &L, void *stream);            // hipLaunchKernel of a resolved launch
 void launch(const Params &p, int game, void *stream);
 const void *flag_kernel_fn();                          // ssd_flag_kernel's host stub (AQL join)
-void launch_wait_counter_kernel(const unsigned long long *counter, unsigned long long target, const uint32_t *abort, void *stream);
+// the stream-side wait of the AQL join: gives up after `timeout_ticks` of the 100 MHz clock and then sets kStWaitTimeout in *status
+void launch_wait_counter_kernel(const unsigned long long *counter, unsigned long long target, const uint32_t *abort,
+                                unsigned long long timeout_ticks, uint32_t *status, void *stream);
 #ifdef SSD_STAMPS
 void launch_clock_kernel(unsigned long long *out, int iters, void *stream);
 #endif

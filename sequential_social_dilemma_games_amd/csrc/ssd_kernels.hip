@@ -28,8 +28,6 @@
 // Reference citations are file:line of the reference repository (social_dilemmas/envs/...).
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "ssd_internal.hpp"
 
 namespace ssd {
@@ -38,7 +36,7 @@ namespace ssd {
 constexpr uint32_t kStBadAction = 1u << 0;
 constexpr uint32_t kStNoSpawn = 1u << 1;
 constexpr uint32_t kStMoveLookup = 1u << 2;
-constexpr uint32_t kStPipeTimeout = 1u << 3;    // a pipelined launch gave up waiting for an env's previous pass
+constexpr uint32_t kStWaitTimeout = 1u << 3;    // the stream-side wait of a rollout's join gave up (ssd_wait_counter_kernel)
 
 // ---------------------------------------------------------------------------------------------
 // shared PRNG (prng.py): triple32 chain
@@ -262,12 +260,12 @@ __host__ size_t lds_bytes(const Params &p, int envs_per_block, bool f32) {
 // round with at most one block per CU (256 CUs), small blocks once CUs run several rounds, and never fewer than
 // 256 blocks when the batch is small.  SSD_ENVS_PER_BLOCK overrides (tuning).
 static int forced_epb_early() {
-    static const int forced = [] { const char *v = getenv("SSD_ENVS_PER_BLOCK"); return v ? atoi(v) : 0; }();
+    static const int forced = SSD_KNOB("SSD_ENVS_PER_BLOCK", 0);
     return forced;
 }
 __host__ int envs_per_block(const Params &p, bool f32) {
     const int E = p.E - p.e_begin;
-    static const int forced = [] { const char *v = getenv("SSD_ENVS_PER_BLOCK"); return v ? atoi(v) : 0; }();
+    static const int forced = SSD_KNOB("SSD_ENVS_PER_BLOCK", 0);
     auto pow2floor = [](int x) { int p = 1; while (p * 2 <= x) p *= 2; return p; };
     int fill = pow2floor(E / 256 > 0 ? E / 256 : 1);            // keep >= 256 blocks
     int rounds = pow2floor(65536 / E > 2 ? 65536 / E : 2);      // 16 at 4096 envs, 8 at 8192, ... 2 from 32768 on
@@ -292,16 +290,12 @@ constexpr FastMap kFastMap[2][3] = {
     {{0, 0, 0, 0, 0, 0, 0, 0}, {16, 38, 45, 720, 336, 320, 155, 0}, {25, 38, 45, 1136, 336, 320, 252, 0}},
     {{0, 0, 0, 0, 0, 0, 0, 0}, {25, 18, 25, 640, 192, 176, 103, 119}, {48, 36, 43, 2064, 320, 304, 412, 476}}};
 
-// PIPE: a launch of a pipelined rollout (ssd_rollout_random, step launches alternating between two streams): instead of
-// stream order, every env's wave waits until that env's previous pass has published its state (flag = pass number, agent-
-// scope release / acquire), and publishes its own right after the write-back -- before it renders the observations.  Waves
-// of step k+1 thus start env by env while step k's slower waves are still at work, and the ~1.5 us between dependent
-// launches disappears from the critical path.  The wait is bounded: a wave that gives up sets kStPipeTimeout.
-// PIPE = 2 ("coherent"): the memory discipline of PIPE without the counters.  The env's state, rewards, dones and
-// observations move with agent-scope (sc1) accesses only: nothing of a launch stays dirty in an XCD's L2 and nothing is read
-// through a CU's L1, so consecutive launches of a chain need no cache write-back / invalidate between them -- the library's own
-// dispatch queues (ssd_aql.hip) then order them with the packet's barrier bit alone (release fence NONE: -0.85 us per step).
-template <int GAME, int MODE, bool F32, int NA, bool STD, int FAST, int PIPE = 0>
+// COH ("coherent"): the env's state, rewards, dones and observations move with agent-scope (sc1) accesses only: nothing of a
+// launch stays dirty in an XCD's L2 and nothing is read through a CU's L1, so consecutive launches of a chain need no cache
+// write-back / invalidate between them -- the library's own dispatch queues (ssd_aql.hip) then order them with the packet's
+// barrier bit alone (release fence NONE: -0.85 us per step).  (Round 2 also had a variant whose waves waited env by env on pass
+// counters, "pipelined launches": 4.44 against 4.50 us per step at 2048 envs, nothing at 4096 -- removed in round 3.)
+template <int GAME, int MODE, bool F32, int NA, bool STD, int FAST, bool COH = false>
 // The leading arguments repeat the Params fields the first global loads need (14 dwords).  Built with
 // -mllvm -amdgpu-kernarg-preload-count=14 the command processor delivers them in SGPRs when the wave starts, so the
 // loads of the env's state go out without first waiting ~0.3 us for a scalar load of the kernel arguments.
@@ -348,15 +342,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     uint8_t *s_occ = s_beam + S;
     uint8_t *s_view = roll ? s_occ + S + A0 : s_world;              // what the observations read: world <- agents <- beams
 
-    constexpr bool kCoh = PIPE != 0;                                 // state through memory with sc1 accesses
-    constexpr bool kFlag = PIPE == 1;                                // ... and ordered env by env through pass counters
-    int blk = blockIdx.x;
-    if constexpr (kFlag) blk = (int)((blockIdx.x + p.pipe_seq * p.pipe_rotate) % gridDim.x);   // (test knob; 0 = identity)
+    constexpr bool kCoh = COH;                                       // state through memory with sc1 accesses
+    const int blk = blockIdx.x;
     // ---- renderer role (split rollouts): workgroups behind the launch's first p.blocks_a render the observations of the
     //      PREVIOUS step of their envs, nothing else.  What they show is the state this launch steps FROM (a_world / a_agents: the
     //      env waves of the launch read the same lines and write elsewhere), overlaid with the agents' glyphs and the previous
     //      step's beam marks (p.beam_list_in); or, for the rare step that left one, the overlay snapshot (p.snap_in) ----
-    if constexpr (MODE == kModeStep && PIPE == 2 && STD && NA > 0 && NA % 5 == 0 && !F32 && FAST != 0) {
+    if constexpr (MODE == kModeStep && COH && STD && NA > 0 && NA % 5 == 0 && !F32 && FAST != 0) {
         // (measured: the renderer workgroups FIRST in the grid: 6.44 against 5.33 us per step; renderer waves that start their work
         // out of phase, by up to 0.3 / 0.7 us: 5.56 / 5.53 against 5.35 -- neither role of a launch has slack; the renderer waves
         // of an env in the env's own workgroup, behind its env waves: 5.65 against 5.30, with 2 envs per workgroup 5.40 against 5.33)
@@ -452,25 +444,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
     SSD_NOTE(14, t_entry);
     SSD_STAMP(0);
 
-    bool pipe_timeout = false;
-    if constexpr (kFlag) {
-        if (active) {
-            const uint32_t want = p.pipe_seq - 1u;
-            uint32_t spins = 0;
-            while (__hip_atomic_load(p.pipe_flags + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > 40000u) { pipe_timeout = true; break; }     // (tens of milliseconds: never in a healthy run)
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // (compiler ordering; the state loads below are coherent ones)
-        }
-    }
     if (active) {
         const bool is_agent = lane < N;
         // ---- prologue: every global load of the env is issued before the first use, so the HBM / L2
         //      latency is paid once.  First the loads whose addresses come from the preloaded arguments alone (hdr, agents,
         //      the first 1 KiB of the grid = the whole grid of the shipped maps, the colour table, the apple list), then
         //      the ones that need further kernel arguments (actions, order, waste list).
-        // (PIPE: the env's state may have been written a moment ago by a wave on another XCD, i.e. behind another L2: agent-
+        // (COH: the env's state may have been written a moment ago by a wave on another XCD, i.e. behind another L2: agent-
         // scope loads and stores, dword by dword, instead of cache write-backs / invalidations around ordinary ones)
         auto cload = [](const uint32_t *ptr) -> uint32_t {
             return kCoh ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ptr;
@@ -541,7 +521,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         if (GAME == 1) asm volatile("" ::"s"(p.waste_cells), "s"(n_waste), "s"(p.thr_ca), "s"(p.thr_cw), "s"(p.n_thr), "s"(p.rew), "s"(p.done), "s"(p.horizon));
         else asm volatile("" ::"s"(p.thr_h32[0]), "s"(p.thr_h32[1]), "s"(p.thr_h32[2]), "s"(p.thr_h32[3]), "s"(p.thr_h_always));
         if (stepping && is_agent) {
-            if (p.num_actions_random <= 0) act_in = p.actions[(size_t)e * N + lane];
+            // (caller-supplied actions: a coherent launch reads them past the caches too -- between a chain's launches nothing
+            // invalidates a CU's L1, and the same action buffer may have held another call's actions a moment ago)
+            if (p.num_actions_random <= 0) act_in = (int)cload(reinterpret_cast<const uint32_t *>(p.actions) + (size_t)e * N + lane);
             if (has_order) ord_in = p.order[(size_t)e * N + lane];
         }
 #pragma unroll
@@ -561,7 +543,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         uint32_t key = rfl(hdr.x), t = rfl(hdr.y), episode = rfl(hdr.z);
         if (a_obs) { s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b; }
         if (obs_f32) { reinterpret_cast<float4 *>(s_f32)[lane] = flut; reinterpret_cast<float4 *>(s_f32)[lane + 64] = flut_b; }
-        uint32_t status = pipe_timeout ? kStPipeTimeout : 0u;
+        uint32_t status = 0u;
         uint32_t cell = areg & 0xFFFFu, orient = mode == kModeReset ? 2u : (areg >> 16) & 3u;   // lane = agent index
         int rew = 0;
         // grid -> LDS (16 B per lane); beam and occupancy layers start empty
@@ -619,13 +601,6 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 if (lane < 4) cstore(reinterpret_cast<uint32_t *>(a_hdr + e) + lane,
                                      lane == 0 ? key : lane == 1 ? t : lane == 2 ? episode : (waste_last | (waste_cur << 16)));
                 if (status && lane == 0) atomicOr(p.status, status);
-                // publish: once these stores have completed (they are write-through at agent scope, so no L2 write-back is
-                // needed -- but a workgroup-scope fence alone emits no wait for them) this env's next pass may start
-                if constexpr (kFlag) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) cstore(p.pipe_flags + e, p.pipe_seq);
-                }
                 return;
             }
             for (int i = lane * 16; i < S; i += 64 * 16) {
@@ -648,6 +623,22 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             slot = (uint32_t)(p.step0 % p.ring);
         }
         bool in_reset = roll && to_reset == 0;
+        // A fused rollout with caller-supplied actions (ssd_rollout_actions): step k reads slot (step0 + k) % action_ring of
+        // p.actions [action_ring][E_total][N].  The load for the NEXT step pass goes out at the start of the current pass, so its
+        // round trip to memory is off the env's path.
+        const bool roll_acts = roll && p.action_ring > 0;
+        uint32_t aslot = 0;
+        int act_next = -1;
+        uint32_t ord_next = 0xFFu;
+        auto fetch_action = [&]() {
+            if (is_agent) {
+                const size_t at = ((size_t)aslot * (size_t)p.E_total + (size_t)e) * N + lane;
+                act_next = p.actions[at];
+                if (has_order) ord_next = p.order[at];            // (the action dict's order, per step: same ring)
+            }
+            aslot = aslot + 1 == (uint32_t)p.action_ring ? 0u : aslot + 1;
+        };
+        if (roll_acts) { aslot = (uint32_t)(p.step0 % p.action_ring); fetch_action(); }
         for (;;) {
             const bool is_reset = (roll || auto_mode) ? in_reset : (mode == kModeReset);
             const bool is_step = (roll || auto_mode) ? !in_reset : (mode == kModeStep);
@@ -703,7 +694,12 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 t += 1;
                 // ---- actions (map_env.py:171-173) ----
                 constexpr int kNumActions = GAME == 0 ? 8 : 9;   // harvest.py:44, cleanup.py:70
-                if (roll || p.num_actions_random > 0) {          // rollout.py:64-65 uniform random actions (a rollout launch: always)
+                if (roll_acts) {                                 // (fused rollout, caller-supplied actions: fetched a pass ago)
+                    act = act_next; ord_in = ord_next;
+                    fetch_action();                              // (the slot after the call's last step is read and ignored)
+                    const bool bad = is_agent && (act < -1 || act >= kNumActions);
+                    if (ballot(bad)) { status |= kStBadAction; if (bad) act = -1; }
+                } else if (roll || p.num_actions_random > 0) {   // rollout.py:64-65 uniform random actions
                     const uint32_t pk = phase_key(key, t, kAction);
                     if (is_agent) {
                         act = (int)randint(draw(pk, (uint32_t)lane), (uint32_t)p.num_actions_random);
@@ -1268,7 +1264,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 waste_last = waste_count;
                 if (!roll) {
                     uint32_t render_flags = 0;
-                    if constexpr (stepping && PIPE == 2) {
+                    if constexpr (stepping && COH) {
                         if ((p.snap_mode & 1) && is_step)
                             render_flags = (!keep_beams && beams_in_regs) ? (ballot(b_cov) ? 1u << 20 : 0u) : 1u << 21;
                     }
@@ -1277,7 +1273,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 if (is_agent && is_step) {
                     // compute_reward (:208); get_done -> False (:209); with a horizon set, the episode ends after `horizon` steps
                     const uint8_t dn = (p.horizon > 0 && t >= (uint32_t)p.horizon) ? 1 : 0;
-                    if constexpr (PIPE == 2) {                                          // (write-through: nothing stays dirty in L2)
+                    if constexpr (COH) {                                                // (write-through: nothing stays dirty in L2)
                         if (p.rew) __hip_atomic_store(p.rew + slot_en + (size_t)e * N + lane, rew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (p.done) __hip_atomic_store(p.done + slot_en + (size_t)e * N + lane, dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     } else {
@@ -1302,7 +1298,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             // leave it in a snapshot instead; entry 0xFFFFFFFF tells the renderer so.  The observation phase (1.2 us of a 5.7 us
             // step) thereby leaves the chain of dependent launches.
             bool leave_overlay = false;                       // wave-uniform
-            if constexpr (stepping && PIPE == 2) {
+            if constexpr (stepping && COH) {
                 if ((p.snap_mode & 1) && is_step) {
                     leave_overlay = patch;
                     // (which of the two the step left is said by two spare bits of agent 0's state word, written with the state
@@ -1331,7 +1327,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 *reinterpret_cast<uint32_t *>(s_view + i) = v;
             }
             wave_sync();
-            if constexpr (stepping && PIPE == 2) {
+            if constexpr (stepping && COH) {
                 if ((p.snap_mode & 1) && is_step && !patch) {                 // (the rare form: the overlay as a snapshot)
                     uint8_t *sg = p.snap + (size_t)e * S;
                     for (int i = lane * 16; i < S; i += 64 * 16) {
@@ -1525,7 +1521,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // no wait here -- 5.48 against 5.45 us per step.  Without that release the results are wrong even while every env
         // stays on its XCD: an sc1 load does not return what an earlier launch left dirty in the same L2.)
 #ifndef SSD_EXP_NO_END_WAIT
-        if constexpr (PIPE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (COH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     }
     SSD_STAMP(9);       // observations issued
@@ -1552,9 +1548,9 @@ __global__ void ssd_render_full_kernel(const Params p, int e0, uint8_t *rgb) {
 
 // Host-side handle (the __global__ stub) of one instantiation: what hipLaunchKernel takes, and what names the kernel's
 // descriptor in the code object for the library's own AQL dispatches (ssd_aql.hip).
-template <int GAME, int MODE, bool F32, int NA, bool STD, int FAST, int PIPE = 0>
+template <int GAME, int MODE, bool F32, int NA, bool STD, int FAST, bool COH = false>
 static const void *kernel_fn() {
-    return reinterpret_cast<const void *>(&ssd_env_kernel<GAME, MODE, F32, NA, STD, FAST, PIPE>);
+    return reinterpret_cast<const void *>(&ssd_env_kernel<GAME, MODE, F32, NA, STD, FAST, COH>);
 }
 
 template <int GAME, bool F32, int NA, bool STD, int FAST>
@@ -1567,8 +1563,7 @@ static const void *select_step(const Params &p) {
         return nullptr;
     } else {
         if constexpr (!F32 && FAST != 0) {           // (the kernels rollouts of the known maps use)
-            if (p.pipe_flags) return kernel_fn<GAME, kModeStep, false, NA, STD, FAST, 1>();
-            if (p.coherent) return kernel_fn<GAME, kModeStep, false, NA, STD, FAST, 2>();
+            if (p.coherent) return kernel_fn<GAME, kModeStep, false, NA, STD, FAST, true>();
         }
         return kernel_fn<GAME, kModeStep, F32, NA, STD, FAST>();
     }
@@ -1608,7 +1603,7 @@ static const void *select_game(const Params &p) {
         } else if (std_view) return select_step<GAME, F32, 0, true, 0>(p);
         return select_step<GAME, F32, 0, false, 0>(p);
     } else if (p.mode == kModeReset) {
-        if constexpr (!F32) { if (p.coherent) return kernel_fn<GAME, kModeReset, false, 0, false, 0, 2>(); }
+        if constexpr (!F32) { if (p.coherent) return kernel_fn<GAME, kModeReset, false, 0, false, 0, true>(); }
         return kernel_fn<GAME, kModeReset, F32, 0, false, 0>();
     }
     return kernel_fn<GAME, kModeObserve, F32, 0, false, 0>();
@@ -1618,14 +1613,14 @@ static const void *select_game(const Params &p) {
 // kernel's kernarg segment (KernArgs: 56 bytes of leading arguments the command processor preloads into SGPRs, then Params).
 bool select(const Params &p_in, int game, Launch *out) {
     Params p = p_in;
-    static const int forced_wt = [] { const char *v = getenv("SSD_OBS_WT"); return v ? atoi(v) : -1; }();   // tuning override
+    static const int forced_wt = SSD_HOOK("SSD_OBS_WT", -1);   // (test-hook build: tuning override)
     // per launch (rollouts run two launches at a time); float32 observations are 4x the bytes: a quarter of the envs
     p.obs_wt = forced_wt >= 0 ? forced_wt : ((p.E - p.e_begin) <= (p.obs_f32 ? 4096 : 16384) ? 1 : 0);
     if (p.coherent) p.obs_wt = 1;                   // (a coherent launch leaves nothing dirty in L2)
-    static const int forced_epb = [] { const char *v = getenv("SSD_ENVS_PER_BLOCK"); return v ? atoi(v) : 0; }();
+    static const int forced_epb = SSD_KNOB("SSD_ENVS_PER_BLOCK", 0);
     const bool f32 = p.obs && p.obs_f32;            // the float32-observation variant is a separate instantiation
     int epb = envs_per_block(p, f32);
-    static const int split_epb = [] { const char *v = getenv("SSD_SPLIT_EPB"); return v ? atoi(v) : 4; }();   // tuning
+    static const int split_epb = SSD_HOOK("SSD_SPLIT_EPB", 4);   // (test-hook build: tuning override)
     // split rollouts run twice the waves per launch: smaller workgroups (measured: 4 envs per workgroup 5.23, 8: 5.78 us per step)
     if (p.snap_mode && forced_epb_early() <= 0 && epb > split_epb && split_epb >= 1) epb = split_epb;
     // (raising the issue priority of the env waves over the renderer waves changes nothing: 5.23 - 5.36 us)
@@ -1666,14 +1661,26 @@ __global__ void ssd_flag_kernel(unsigned long long *counter) {
 // ... with this one-wave kernel, launched on that stream: it sleeps and polls (every ~0.4 us, one L2-served load) until the
 // counter has reached `target`, i.e. until every chain of the rollout has finished.  A waiting kernel instead of
 // hipStreamWaitValue64: the command processor polling host memory for the stream slowed the dispatch queues it shares the
-// micro-engine with (6.7 against 6.1 us per 4096-env step).  `abort` (host memory, set when the HSA runtime reports a queue
-// error) ends the wait: the work it waits for will then never come.
-__global__ void ssd_wait_counter_kernel(const unsigned long long *counter, unsigned long long target, const volatile uint32_t *abort) {
+// micro-engine with (6.7 against 6.1 us per 4096-env step).  The wait is BOUNDED: `abort` (host memory, set when the HSA runtime
+// reports a queue error) ends it -- the work it waits for will then never come --, and so does `timeout_ticks` of the 100 MHz
+// constant clock (the caller sizes it from the call: seconds, far beyond any healthy rollout).  A kernel that waits for another
+// queue's kernel never ends under a tool that runs kernels one at a time (rocprofv3 --pmc): the library then uses host waits
+// (ssd_capi.hip, sync mode, chosen automatically when a tool is attached); should it still get here, the wave gives up, sets
+// SSD_ST_WAIT_TIMEOUT in the handle's status word -- the call's results are not in place -- and lets the stream go on.
+__global__ void ssd_wait_counter_kernel(const unsigned long long *counter, unsigned long long target, const volatile uint32_t *abort,
+                                        unsigned long long timeout_ticks, uint32_t *status) {
     if (threadIdx.x != 0) return;
     uint32_t spins = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(16);
-        if ((++spins & 1023u) == 0 && abort && *abort) break;
+        if ((++spins & 1023u) == 0) {
+            if (abort && *abort) break;
+            if (timeout_ticks && __builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+                if (status) atomicOr(status, kStWaitTimeout);
+                break;
+            }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
@@ -1697,8 +1704,10 @@ void launch_clock_kernel(unsigned long long *out, int iters, void *stream) {
 }
 #endif
 const void *flag_kernel_fn() { return reinterpret_cast<const void *>(&ssd_flag_kernel); }
-void launch_wait_counter_kernel(const unsigned long long *counter, unsigned long long target, const uint32_t *abort, void *stream) {
-    hipLaunchKernelGGL(ssd_wait_counter_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), counter, target, abort);
+void launch_wait_counter_kernel(const unsigned long long *counter, unsigned long long target, const uint32_t *abort,
+                                unsigned long long timeout_ticks, uint32_t *status, void *stream) {
+    hipLaunchKernelGGL(ssd_wait_counter_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), counter, target, abort,
+                       timeout_ticks, status);
 }
 void launch_signal_kernel(long long *signal_value, void *stream) {
     hipLaunchKernelGGL(ssd_signal_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), signal_value);

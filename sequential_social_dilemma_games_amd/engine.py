@@ -128,19 +128,21 @@ class VecEngine(object):
         self.steps_since_full_reset = 0 if mask is None else None
         return obs
 
-    def step(self, actions, order=None, out=None, auto_reset=False):
+    def step(self, actions, order=None, out=None, auto_reset=False, chains=False):
         """MapEnv.step (map_env.py:152-212) on every env.  actions: i32 [E,N] (-1 = absent);
         order: optional u8 [E,N] action-dict order.  Returns (obs, rew, done) device tensors.
         auto_reset: envs that reach the horizon (set_horizon) are reset by the same launch, their obs rows are the
-        reset's (SSD_AUTO_RESET; uint8 observations only)."""
+        reset's (SSD_AUTO_RESET; uint8 observations only).
+        chains: dispatch the step like a one-step rollout_actions() call (SSD_STEP_CHAINS: env ranges stepped concurrently
+        through the library's own queues); index action order, no auto_reset."""
         torch, dev = self._torch()
         self._check_tensor(actions, (self.E, self.N), torch.int32, "actions")
         if order is not None:
             self._check_tensor(order, (self.E, self.N), torch.uint8, "order")
         obs, rew, done = out if out is not None else self.alloc_outputs()
         _capi.check(self._L.ssd_step(self._h, self._dp(actions), self._dp(order), self._dp(obs), self._dp(rew),
-                                     self._dp(done), self._obs_flags(obs) | (_capi.SSD_AUTO_RESET if auto_reset else 0),
-                                     self._stream()), self._h)
+                                     self._dp(done), self._obs_flags(obs) | (_capi.SSD_AUTO_RESET if auto_reset else 0)
+                                     | (_capi.SSD_STEP_CHAINS if chains else 0), self._stream()), self._h)
         self._count_after_step(auto_reset)
         return obs, rew, done
 
@@ -175,38 +177,29 @@ class VecEngine(object):
         """How many independent env ranges rollout_random() enqueues on streams of its own (0 = automatic)."""
         _capi.check(self._L.ssd_set_rollout_chains(self._h, int(chains)), self._h)
 
-    def rollout_random(self, n_steps, obs, rew=None, done=None, reset_every=0, step0=0, num_actions=None, fused=False,
-                       pipelined=False):
-        """rollout.py:58-70 as ONE library call: `n_steps` random-action steps (plus a full reset whenever
-        (step0 + k) % reset_every == 0) enqueued back to back.  obs / rew / done are device tensors with a leading ring
-        dimension R: step k writes slot (step0 + k) % R  (obs u8 or f32 [R,E,N,V,V,3], rew i32 [R,E,N], done u8 [R,E,N]).
-        Same launches as n_steps calls of step_random(); the host just stops being the bottleneck.
-        fused=True: ONE kernel launch for the whole call (SSD_ROLLOUT_FUSED) -- every env stays in LDS / registers across
-        its steps; same results, uint8 observations only.
-        pipelined=True: ask for SSD_ROLLOUT_PIPELINED (step k+1 starts env by env while step k's slower envs are still at
-        work; needs a ring of at least 2 slots and pays up to 2048 envs -- see include/ssd.h)."""
+    def _rollout_args(self, obs, rew, done):
         # (the buffers of the last call again: their checks and pointers are known -- a short call is mostly fixed costs)
         cache = getattr(self, "_roll_cache", None)
         if cache is not None and cache[0] is obs and cache[1] is rew and cache[2] is done:
-            po, pr, pd, ring, f32 = cache[3]
-        else:
-            torch, dev = self._torch()
-            ring = int(obs.shape[0])
+            return cache[3]
+        torch, dev = self._torch()
+        first = obs if obs is not None else rew if rew is not None else done
+        if first is None:
+            raise ValueError("a rollout needs at least one of obs / rew / done (their leading dimension is the output ring)")
+        ring = int(first.shape[0])
+        if obs is not None:
             if obs.dtype not in (torch.uint8, torch.float32):
                 raise ValueError("obs must be uint8 or float32")
             self._check_tensor(obs, (ring, self.E, self.N, self.V, self.V, 3), obs.dtype, "obs")
-            if rew is not None:
-                self._check_tensor(rew, (ring, self.E, self.N), torch.int32, "rew")
-            if done is not None:
-                self._check_tensor(done, (ring, self.E, self.N), torch.uint8, "done")
-            po, pr, pd, f32 = self._dp(obs), self._dp(rew), self._dp(done), (_capi.SSD_OBS_F32 if obs.dtype == torch.float32 else 0)
-            self._roll_cache = (obs, rew, done, (po, pr, pd, ring, f32))
-        na = self.num_actions if num_actions is None else int(num_actions)
-        rc = self._L.ssd_rollout_random(self._h, na, int(n_steps), int(reset_every), int(step0), po, pr, pd, ring,
-                                        f32 | (_capi.SSD_ROLLOUT_FUSED if fused else 0) | (_capi.SSD_ROLLOUT_PIPELINED if pipelined else 0),
-                                        self._stream())
-        if rc:
-            _capi.check(rc, self._h)
+        if rew is not None:
+            self._check_tensor(rew, (ring, self.E, self.N), torch.int32, "rew")
+        if done is not None:
+            self._check_tensor(done, (ring, self.E, self.N), torch.uint8, "done")
+        args = (self._dp(obs), self._dp(rew), self._dp(done), ring, (_capi.SSD_OBS_F32 if obs is not None and obs.dtype == torch.float32 else 0))
+        self._roll_cache = (obs, rew, done, args)
+        return args
+
+    def _count_rollout(self, n_steps, reset_every, step0):
         n_steps, reset_every, step0 = int(n_steps), int(reset_every), int(step0)
         last = None                                  # index of the last step of this call that a full reset preceded
         if reset_every > 0 and n_steps > 0:
@@ -217,12 +210,53 @@ class VecEngine(object):
         else:
             self._count_steps(n_steps)
 
+    def rollout_random(self, n_steps, obs, rew=None, done=None, reset_every=0, step0=0, num_actions=None, fused=False):
+        """rollout.py:58-70 as ONE library call: `n_steps` random-action steps (plus a full reset whenever
+        (step0 + k) % reset_every == 0) enqueued back to back.  obs / rew / done are device tensors with a leading ring
+        dimension R: step k writes slot (step0 + k) % R  (obs u8 or f32 [R,E,N,V,V,3], rew i32 [R,E,N], done u8 [R,E,N]).
+        Same launches as n_steps calls of step_random(); the host just stops being the bottleneck.
+        fused=True: ONE kernel launch for the whole call (SSD_ROLLOUT_FUSED) -- every env stays in LDS / registers across
+        its steps; same results, uint8 observations only."""
+        po, pr, pd, ring, f32 = self._rollout_args(obs, rew, done)
+        na = self.num_actions if num_actions is None else int(num_actions)
+        rc = self._L.ssd_rollout_random(self._h, na, int(n_steps), int(reset_every), int(step0), po, pr, pd, ring,
+                                        f32 | (_capi.SSD_ROLLOUT_FUSED if fused else 0), self._stream())
+        if rc:
+            _capi.check(rc, self._h)
+        self._count_rollout(n_steps, reset_every, step0)
+
+    def rollout_actions(self, actions, n_steps, obs, rew=None, done=None, reset_every=0, step0=0, fused=False, order=None):
+        """The same call with caller-supplied actions (ssd_rollout_actions): what the reference's callers do, env.step(policy
+        actions) per step (visuallizer_rllib.py:121-153), for a recorded sequence / an action chunk of n_steps steps.
+        actions: int32 [A,E,N] device tensor (-1 = the agent does not act); step k reads slot (step0 + k) % A.  order: optional
+        uint8 [A,E,N], per step the agent indices in action-dict order, 0xFF-terminated (None: index order).  Outputs as
+        rollout_random().  Reuse the same action / output tensors from call to call: the launches' arguments are cached by them."""
+        torch, dev = self._torch()
+        cache = getattr(self, "_act_cache", None)
+        if cache is not None and cache[0] is actions and cache[1] is order:
+            pa, pord, aring = cache[2]
+        else:
+            aring = int(actions.shape[0])
+            self._check_tensor(actions, (aring, self.E, self.N), torch.int32, "actions")
+            if order is not None:
+                self._check_tensor(order, (aring, self.E, self.N), torch.uint8, "order")
+            pa, pord = self._dp(actions), self._dp(order)
+            self._act_cache = (actions, order, (pa, pord, aring))
+        po, pr, pd, ring, f32 = self._rollout_args(obs, rew, done)
+        rc = self._L.ssd_rollout_actions(self._h, pa, pord, aring, int(n_steps), int(reset_every), int(step0), po, pr, pd, ring,
+                                         f32 | (_capi.SSD_ROLLOUT_FUSED if fused else 0), self._stream())
+        if rc:
+            _capi.check(rc, self._h)
+        self._count_rollout(n_steps, reset_every, step0)
+
     def rollout_path(self):
-        """How the last rollout_random() call was dispatched: {"aql", "coherent", "split", "fused", "pipelined": bool, "chains": n}
-        (ssd_rollout_path) -- lets a benchmark or a test tell a silent fallback from the path it meant to measure."""
+        """How the last rollout call was dispatched (ssd_rollout_path): {"aql", "coherent", "split", "fused", "sync", "forked",
+        "queue_dropped": bool, "chains": n, "pool": dispatch queues the device's pool settled on} -- lets a benchmark or a test
+        tell a silent fallback from the path it meant to measure."""
         m = self._L.ssd_rollout_path(self._h)
         return {"aql": bool(m & _capi.SSD_PATH_AQL), "coherent": bool(m & _capi.SSD_PATH_COHERENT), "split": bool(m & _capi.SSD_PATH_SPLIT),
-                "fused": bool(m & _capi.SSD_PATH_FUSED), "pipelined": bool(m & _capi.SSD_PATH_PIPELINED), "chains": (m >> 8) & 15}
+                "fused": bool(m & _capi.SSD_PATH_FUSED), "sync": bool(m & _capi.SSD_PATH_SYNC), "forked": bool(m & _capi.SSD_PATH_FORKED),
+                "queue_dropped": bool(m & _capi.SSD_PATH_QUEUE_DROPPED), "chains": (m >> 8) & 15, "pool": (m >> 12) & 7}
 
     def observe(self, rotate=True, obs=None):
         torch, dev = self._torch()

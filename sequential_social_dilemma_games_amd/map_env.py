@@ -178,12 +178,8 @@ class MapEnv(MultiAgentEnv):
             self.agents[agent.agent_id] = agent
 
     def ascii_to_numpy(self, ascii_list):
-        """map_env.py:132-150."""
-        arr = np.full((len(ascii_list), len(ascii_list[0])), ' ')
-        for row in range(arr.shape[0]):
-            for col in range(arr.shape[1]):
-                arr[row, col] = ascii_list[row][col]
-        return arr
+        """The ASCII rows as a '<U1' character grid (what map_env.py:132-150 builds cell by cell)."""
+        return np.array([list(line) for line in ascii_list], dtype='<U1')
 
     @staticmethod
     def _to_chars(grid_i8):
@@ -294,11 +290,18 @@ class MapEnv(MultiAgentEnv):
             map = self.get_map_with_agents()
         if color_map is None:
             color_map = self.color_map
-        rgb_arr = np.zeros((map.shape[0], map.shape[1], 3), dtype=int)
-        for row_elem in range(map.shape[0]):
-            for col_elem in range(map.shape[1]):
-                rgb_arr[row_elem, col_elem, :] = color_map[map[row_elem, col_elem]]
-        return rgb_arr
+        # one table lookup for the whole grid: glyph code point -> RGB row (a glyph without a colour is a KeyError, as it is
+        # when the reference indexes its dict cell by cell)
+        glyphs = np.asarray(map, dtype='<U1')
+        codes = np.ascontiguousarray(glyphs).view(np.uint32).reshape(glyphs.shape)
+        for code in np.unique(codes):
+            if chr(int(code)) not in color_map:
+                raise KeyError(chr(int(code)))
+        table = np.zeros((int(codes.max()) + 1 if codes.size else 1, 3), dtype=int)
+        for glyph, rgb in color_map.items():
+            if ord(glyph) < table.shape[0]:
+                table[ord(glyph)] = rgb
+        return table[codes]
 
     def render(self, filename=None):
         """map_env.py:341-355."""
@@ -310,16 +313,12 @@ class MapEnv(MultiAgentEnv):
             plt.savefig(filename)
 
     def rotate_view(self, orientation, view):
-        """map_env.py:669-689."""
-        if orientation == 'UP':
-            return view
-        elif orientation == 'LEFT':
-            return np.rot90(view, k=1, axes=(0, 1))
-        elif orientation == 'DOWN':
-            return np.rot90(view, k=2, axes=(0, 1))
-        elif orientation == 'RIGHT':
-            return np.rot90(view, k=3, axes=(0, 1))
-        raise ValueError('Orientation {} is not valid'.format(orientation))
+        """Quarter turns of the egocentric view by orientation (map_env.py:669-689): UP 0, LEFT 1, DOWN 2, RIGHT 3."""
+        quarter_turns = {'UP': 0, 'LEFT': 1, 'DOWN': 2, 'RIGHT': 3}
+        if orientation not in quarter_turns:
+            raise ValueError('Orientation {} is not valid'.format(orientation))
+        k = quarter_turns[orientation]
+        return view if k == 0 else np.rot90(view, k)
 
     def find_visible_agents(self, agent_id):
         """map_env.py:749-770.  The reference compares the agent's OWN position with its window for every

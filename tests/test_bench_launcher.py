@@ -42,3 +42,39 @@ def test_rank_count_mismatch_is_an_error_not_a_warning():
     p = _run(["--gpus", "2", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0
     assert b"ranks" in p.stderr
+
+
+def test_a_failing_optional_leg_does_not_cost_the_headline():
+    """bench.py prints its one line whatever happens in an optional leg.  The legs run inside run_leg(): an
+    exception (SSD_BENCH_FAIL_LEG injects one) lands as {"error": ...} in that leg's slot, the other legs run, the line goes out,
+    exit status 0.  Here on the legs that need no GPU (--dry-run --dry-run-legs); tests/test_multiprocess_gpu.py does the same
+    with the real legs on the GPU box."""
+    p = _run(["--gpus", "1", "--dry-run", "--dry-run-legs", "--envs", "64"], env_extra={"SSD_BENCH_FAIL_LEG": "configs"})
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    assert res["shards"] == [[0, 64]]                                  # the "headline" of a dry run
+    assert "injected failure" in res["configs"]["error"]
+    assert res["cpu_baseline"]["value"] > 0 and res["cpu_baseline"]["kind"] == "port"   # the leg after the failing one still ran
+    assert b"optional leg 'configs' failed" in p.stderr
+    p = _run(["--gpus", "1", "--dry-run", "--dry-run-legs", "--envs", "64"], env_extra={"SSD_BENCH_FAIL_LEG": "cpu_baseline,configs"})
+    res = json.loads(p.stdout.decode())
+    assert p.returncode == 0 and "error" in res["cpu_baseline"] and "error" in res["configs"] and res["n_gpus"] == 1
+
+
+def test_run_leg_catches_system_exit_and_memory_error():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    res = {"value": 1.0}
+
+    def boom(exc):
+        def f():
+            raise exc
+        return f
+    assert bench.run_leg(res, "a", boom(SystemExit("status word"))) is False
+    assert bench.run_leg(res, "b", boom(MemoryError("hipMalloc"))) is False
+    assert bench.run_leg(res, "c", lambda: {"ok": 1}) is True
+    assert res["value"] == 1.0 and "SystemExit" in res["a"]["error"] and "MemoryError" in res["b"]["error"] and res["c"] == {"ok": 1}

@@ -65,11 +65,54 @@ def test_python_constants_match_the_header():
         expr = m.group(1).strip().replace("u", "")
         return int(eval(expr))                                   # "1 << 3", "-2", ...
 
-    for name in ("SSD_HOST_PTRS", "SSD_NO_ROTATE", "SSD_OBS_F32", "SSD_ROLLOUT_FUSED", "SSD_AUTO_RESET", "SSD_ROLLOUT_PIPELINED"):
+    for name in ("SSD_HOST_PTRS", "SSD_NO_ROTATE", "SSD_OBS_F32", "SSD_ROLLOUT_FUSED", "SSD_AUTO_RESET", "SSD_STEP_CHAINS"):
         assert getattr(_capi, name) == value(name), name
-    for name in ("SSD_ST_BAD_ACTION", "SSD_ST_NO_SPAWN", "SSD_ST_MOVE_LOOKUP", "SSD_ST_PIPE_TIMEOUT"):
+    for name in ("SSD_ST_BAD_ACTION", "SSD_ST_NO_SPAWN", "SSD_ST_MOVE_LOOKUP", "SSD_ST_WAIT_TIMEOUT"):
         assert getattr(_capi, name) == value(name), name
-    for name in ("SSD_PATH_AQL", "SSD_PATH_COHERENT", "SSD_PATH_SPLIT", "SSD_PATH_FUSED", "SSD_PATH_PIPELINED"):
+    for name in ("SSD_PATH_AQL", "SSD_PATH_COHERENT", "SSD_PATH_SPLIT", "SSD_PATH_FUSED", "SSD_PATH_SYNC", "SSD_PATH_QUEUE_DROPPED", "SSD_PATH_FORKED"):
         assert getattr(_capi, name) == value(name), name
     assert value("SSD_OK") == 0 and value("SSD_E_DEVICE") == -2
     assert int(re.search(r"#define SSD_ABI_VERSION (\d+)", text).group(1)) == _capi.lib().ssd_abi_version()
+
+
+def test_product_library_reads_only_the_documented_knobs():
+    """the shipped library honours the safe, documented environment variables only (the table in include/ssd.h);
+    knobs that can change results -- fence scopes, forced forks, alternating geometries -- exist in the test-hook build alone."""
+    import subprocess
+    pkg = os.path.join(REPO, "sequential_social_dilemma_games_amd")
+    documented = {"SSD_AQL", "SSD_AQL_COHERENT", "SSD_AQL_SPLIT", "SSD_AQL_SYNC", "SSD_AQL_QUEUES", "SSD_ROLLOUT_CHAINS",
+                  "SSD_ENVS_PER_BLOCK", "SSD_AQL_VERBOSE"}
+    header = open(os.path.join(REPO, "include", "ssd.h")).read()
+    for k in documented:
+        assert re.search(r"\b%s\b" % k, header), "%s is not in the header's table" % k
+    out = subprocess.run(["strings", os.path.join(pkg, "libssd_hip.so")], stdout=subprocess.PIPE, check=True).stdout.decode()
+    found = set(re.findall(r"SSD_[A-Z][A-Z_0-9]*", out))
+    assert found == documented, found ^ documented
+    hooks = os.path.join(pkg, "libssd_hip_testhooks.so")
+    assert os.path.exists(hooks), "make testhooks"
+    out = subprocess.run(["strings", hooks], stdout=subprocess.PIPE, check=True).stdout.decode()
+    more = set(re.findall(r"SSD_[A-Z][A-Z_0-9]*", out))
+    assert {"SSD_AQL_ACQ", "SSD_AQL_REL", "SSD_AQL_ALTERNATE", "SSD_AQL_ALWAYS_FORK"} <= more and documented <= more
+
+
+@pytest.mark.parametrize("var,want", [(None, 0), ("ROCP_TOOL_LIBRARIES", 1), ("HSA_TOOLS_LIB", 1), ("ROCPROF_COUNTER_COLLECTION", 1),
+                                      ("LD_PRELOAD_NAME", 1)])
+def test_profiler_detection(var, want):
+    """with a profiling tool attached the rollout calls must not make kernels wait for other queues' kernels
+    (such tools may run kernels one at a time).  ssd_profiler_attached() is the rule the library applies: the ROCm tools'
+    environment variables, or their libraries already loaded.  Needs no device."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS")) and k != "LD_PRELOAD"}
+    # (the variable is set AFTER the library -- and with it the HIP runtime -- has loaded: the runtime itself acts on these
+    # variables when it loads, and a made-up tool path makes it abort; the rule under test only reads the text)
+    name = "LD_PRELOAD" if var == "LD_PRELOAD_NAME" else var
+    value = {"LD_PRELOAD_NAME": "librocprofiler-sdk-tool.so", "ROCPROF_COUNTER_COLLECTION": "1"}.get(var, "/nonexistent/libtool.so")
+    code = ("import os, sys; sys.path.insert(0, %r); from sequential_social_dilemma_games_amd import _capi; L = _capi.lib(); "
+            "assert L.ssd_profiler_attached() == 0; " % REPO)
+    if var:
+        code += "os.environ[%r] = %r; " % (name, value)
+    code += "print(L.ssd_profiler_attached())"
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert int(r.stdout.decode().strip().splitlines()[-1]) == want

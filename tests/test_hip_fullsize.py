@@ -41,64 +41,25 @@ def test_full_size_rollout_is_bit_exact_against_the_oracle(game):
     assert eng.status() == 0
 
 
-@pytest.mark.parametrize("game", [K.GAME_HARVEST, K.GAME_CLEANUP])
-def test_pipelined_rollout_under_load_is_bit_exact(game):
-    """SSD_ROLLOUT_PIPELINED at the largest batch it accepts of the shipped maps' order (2048 envs: configs[4]'s per-GPU
-    share): two launches in flight, every env's wave handing its state to the next step's wave through memory.  150 steps
-    with a reset in the middle; the last ring slots and the final state equal the oracle's, no wave timed out.  (A missing
-    wait before the hand-over flag shows up here and not with a few hundred envs.)"""
-    import torch
-    amap = K.HARVEST_MAP if game == K.GAME_HARVEST else K.CLEANUP_MAP
-    E, N, ring, every, steps = 2048, 5, 2, 97, 150
-    eng = VecEngine(game, amap, num_envs=E, num_agents=N, seed=12)
-    ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), seed=12)
-    obs = torch.zeros((ring, E, N, 15, 15, 3), dtype=torch.uint8, device="cuda")
-    rew = torch.zeros((ring, E, N), dtype=torch.int32, device="cuda")
-    eng.rollout_random(steps, obs, rew, None, reset_every=every, step0=0, pipelined=True)
-    want = {}
-    for k in range(steps):
-        if k % every == 0:
-            ora.reset()
-        _, o_obs, o_rew, _ = ora.step_random(want_obs=(k >= steps - ring))
-        want[k] = (o_obs, o_rew)
-    got_obs, got_rew = obs.cpu().numpy(), rew.cpu().numpy()
-    for k in range(steps - ring, steps):
-        np.testing.assert_array_equal(got_rew[k % ring], want[k][1], err_msg="rew of step %d" % k)
-        assert np.array_equal(got_obs[k % ring], want[k][0]), "observations of step %d differ" % k
-    a, b = eng.get_state(), ora.get_state()
-    for key in ("world", "pos", "orient", "episode", "t"):
-        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
-    assert eng.status() == 0
-
-
-def test_pipelined_handover_between_xcds():
-    """The pipelined kernels hand an env's state from one wave to the next through memory with agent-scope accesses.
-    SSD_PIPE_ROTATE shifts the env -> workgroup mapping by one workgroup per launch, so that every env changes XCD (and
-    with it the L2 it sits behind) at every step: still bit-exact against the oracle.  (A process of its own: the knob is
-    read once per process.)"""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SSD_PIPE_ROTATE="1", SSD_ROLLOUT_PIPELINE="1", SOAK_RING="2")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_parity.py"), "cleanup", "1024", "400", "50", "chains"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
-    out = r.stdout.decode(errors="replace")
-    assert r.returncode == 0 and "soak ok" in out, out[-2000:]
+HOOKS_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sequential_social_dilemma_games_amd",
+                         "libssd_hip_testhooks.so")
 
 
 @pytest.mark.parametrize("knobs", [dict(SSD_AQL_ALTERNATE="1", SSD_AQL_ALWAYS_FORK="1"),
                                    dict(SSD_AQL_ALTERNATE="1", SSD_AQL_SPLIT="0"),
                                    dict(SSD_AQL_COHERENT="0"), dict(SSD_AQL="0")])
+@pytest.mark.parametrize("how", ["chains", "actions"])
 @pytest.mark.parametrize("game", ["harvest", "cleanup"])
-def test_rollout_dispatch_modes_when_envs_change_xcd(game, knobs):
-    """The coherent chains of ssd_rollout_random carry no cache write-back or invalidate between launches: an env's state --
-    and, in split rollouts, the snapshot its observations are rendered from -- must reach the next launch through memory
+def test_rollout_dispatch_modes_when_envs_change_xcd(game, how, knobs):
+    """The coherent chains of the rollout calls carry no cache write-back or invalidate between launches: an env's state --
+    and, in split rollouts, the beam list its observations are rendered from -- must reach the next launch through memory
     wherever that launch's wave runs.  SSD_AQL_ALTERNATE halves the envs per workgroup on odd steps, so that most envs change
     workgroup, and with it XCD and L2, from every launch to the next (and the renderer workgroups of a launch read what the
-    OTHER mapping wrote); SSD_AQL_ALWAYS_FORK makes every call fork from its stream.  4096 envs x 600 steps as rollout chains,
-    checked against the oracle every 100 steps.  Also: the same without split rendering, the plain kernels behind agent-scope
-    fences, and the hipLaunchKernel path (a process of its own each: the knobs are read once per process)."""
+    OTHER mapping wrote); SSD_AQL_ALWAYS_FORK makes every call fork from its stream.  4096 envs x 600 steps as rollout chains
+    (device-drawn actions, and caller-supplied ones: ssd_rollout_actions), checked against the oracle every 100 steps.  Also:
+    the same without split rendering, the plain kernels behind agent-scope fences, and the hipLaunchKernel path.  A process of
+    its own each (the knobs are read once per process); the two test hooks exist in the test-hook build of the library only
+    (libssd_hip_testhooks.so: the product sources with -DSSD_TESTHOOKS), which is what these processes load."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -106,17 +67,17 @@ def test_rollout_dispatch_modes_when_envs_change_xcd(game, knobs):
     for k in ("SSD_AQL", "SSD_AQL_ALTERNATE", "SSD_AQL_ALWAYS_FORK", "SSD_AQL_SPLIT", "SSD_AQL_COHERENT"):
         env.pop(k, None)
     env.update(knobs)
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_parity.py"), game, "4096", "600", "100", "chains"],
+    env["SSD_LIB_PATH"] = HOOKS_LIB
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_parity.py"), game, "4096", "600", "100", how],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and "soak ok" in out, out[-2000:]
 
 
-def test_pipelined_wait_is_bounded():
-    """A wave of a pipelined launch that waits in vain gives up after a bounded number of polls, sets SSD_ST_PIPE_TIMEOUT and
-    lets its launch finish.  SSD_PIPE_TEST_STALL makes the first launch of a call wait for a pass that never ran (a process
-    of its own: the knob is read once per process)."""
-    import os
+def test_join_wait_is_bounded():
+    """the stream-side wait of a rollout's join (a one-wave kernel polling a counter the library's queues
+    bump) must not be able to spin forever.  Test hook SSD_AQL_TEST_LOST_JOIN makes it wait for a count that never comes, with
+    the time bound cut to 50 ms: the wave gives up, sets SSD_ST_WAIT_TIMEOUT and the stream goes on; the next call works."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -130,16 +91,31 @@ def test_pipelined_wait_is_bounded():
         "eng.reset()\n"
         "torch.cuda.synchronize()\n"
         "t0 = time.time()\n"
-        "eng.rollout_random(6, obs, None, None, reset_every=0, step0=0, pipelined=True)\n"
+        "eng.rollout_random(6, obs, None, None, reset_every=0, step0=0)\n"
         "torch.cuda.synchronize()\n"
+        "assert eng.rollout_path()['aql'] and not eng.rollout_path()['sync']\n"
         "st = eng.status()\n"
         "print('status', st, 'seconds', round(time.time() - t0, 3))\n"
-        "assert st & _capi.SSD_ST_PIPE_TIMEOUT, st\n"
+        "assert st & _capi.SSD_ST_WAIT_TIMEOUT, st\n"
         "assert time.time() - t0 < 5.0\n" % root)
-    env = dict(os.environ, SSD_PIPE_TEST_STALL="1")
+    env = dict(os.environ, SSD_AQL_TEST_LOST_JOIN="1", SSD_AQL_TEST_TIMEOUT_MS="50", SSD_LIB_PATH=HOOKS_LIB)
+    env.pop("SSD_AQL_SYNC", None)
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and "status" in out, out[-2000:]
+
+
+def test_sync_mode_gives_the_same_results():
+    """With a profiling tool attached (or SSD_AQL_SYNC=1) the rollout calls wait on the host instead of with kernels that wait
+    for other queues' kernels (rocprofv3 --pmc runs kernels one at a time).  Same launches, same results; the path says so."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSD_AQL_SYNC="1", SOAK_EXPECT_PATH="sync")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_parity.py"), "cleanup", "4096", "200", "50", "chains"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "soak ok" in out, out[-2000:]
 
 
 def test_shard_invariance_and_determinism():
@@ -217,24 +193,32 @@ def test_step_observation_equals_observe_of_the_stored_state():
     assert not (unrot == again).all().item()
 
 
-def _rollout_vs_oracle(game, amap, E, N, seed, steps, step0, every, ring, chains, **kw):
-    """ssd_rollout_random on a fresh engine against the oracle stepped call by call: the last `ring` steps' observations and
-    rewards, and the final state."""
+def _rollout_vs_oracle(game, amap, E, N, seed, steps, step0, every, ring, chains, actions=False, env_base=0, **kw):
+    """ssd_rollout_random (actions=True: ssd_rollout_actions with a random action tensor) on a fresh engine against the oracle
+    stepped call by call: the last `ring` steps' observations and rewards, and the final state."""
     import torch
-    eng = VecEngine(game, amap, num_envs=E, num_agents=N, seed=seed)
-    ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), seed=seed)
+    eng = VecEngine(game, amap, num_envs=E, num_agents=N, seed=seed, env_index_base=env_base)
+    ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), seed=seed, env_base=env_base)
     eng.set_rollout_chains(chains)
     obs = torch.zeros((ring, E, N, 15, 15, 3), dtype=torch.uint8, device="cuda")
     rew = torch.zeros((ring, E, N), dtype=torch.int32, device="cuda")
     done = torch.ones((ring, E, N), dtype=torch.uint8, device="cuda")
     eng.reset()
     ora.reset()
-    eng.rollout_random(steps, obs, rew, done, reset_every=every, step0=step0, **kw)
+    if actions:
+        a_host = np.random.RandomState(seed).randint(-1, 8 if game == K.GAME_HARVEST else 9, size=(steps, E, N)).astype(np.int32)
+        a_dev = torch.from_numpy(a_host).cuda()
+        eng.rollout_actions(a_dev, steps, obs, rew, done, reset_every=every, step0=step0, **kw)
+    else:
+        eng.rollout_random(steps, obs, rew, done, reset_every=every, step0=step0, **kw)
     want = {}
     for k in range(step0, step0 + steps):
         if every and k % every == 0:
             ora.reset()
-        _, o_obs, o_rew, _ = ora.step_random(want_obs=(k >= step0 + steps - ring))
+        if actions:
+            o_obs, o_rew, _ = ora.step(a_host[k % steps])
+        else:
+            _, o_obs, o_rew, _ = ora.step_random(want_obs=(k >= step0 + steps - ring))
         want[k] = (o_obs, o_rew)
     g_obs, g_rew = obs.cpu().numpy(), rew.cpu().numpy()
     for k in range(step0 + steps - ring, step0 + steps):
@@ -271,6 +255,18 @@ def test_the_exact_bench_path_at_full_size(game):
     _rollout_vs_oracle(game, amap, 4096, 5, seed=0, steps=45, step0=975, every=1000, ring=1, chains=2)
 
 
+@pytest.mark.parametrize("cfg", ["harvest_rank7_of_configs3", "cleanup48x36_rank7_of_configs4"])
+def test_the_last_ranks_shards_of_the_multi_gpu_configurations(cfg):
+    """the env index offsets of the 8-GPU configurations never met the oracle (the PRNG key hashes the GLOBAL
+    env index: ssd_config.env_index_base).  Rank 7 of configs[3] (Harvest, 32768 envs over 8 GPUs: envs 28672 .. 32767) and of
+    configs[4] (Cleanup 48x36, 10 agents, 16384 envs: envs 14336 .. 16383) as bench.py steps them -- ssd_rollout_random, automatic
+    chains, a reset at step 0 -- against the oracle built with the same offset."""
+    if cfg.startswith("harvest"):
+        _rollout_vs_oracle(K.GAME_HARVEST, K.HARVEST_MAP, 4096, 5, seed=0, steps=10, step0=0, every=1000, ring=1, chains=0, env_base=28672)
+    else:
+        _rollout_vs_oracle(K.GAME_CLEANUP, K.cleanup_map_48x36(), 2048, 10, seed=0, steps=10, step0=0, every=1000, ring=1, chains=0, env_base=14336)
+
+
 def test_the_bench_configuration_takes_the_native_dispatch_path():
     """What bench.py reports must be what it meant to measure: at the headline configuration a rollout call goes through the
     library's own dispatch queues with the coherent kernel variant and split rendering (ssd_rollout_path) -- unless the
@@ -280,29 +276,38 @@ def test_the_bench_configuration_takes_the_native_dispatch_path():
     out = eng.alloc_outputs()
     ring = tuple(t.unsqueeze(0) for t in out)
     eng.set_rollout_chains(2)
-    assert eng.rollout_path() == {"aql": False, "coherent": False, "split": False, "fused": False, "pipelined": False, "chains": 0}
+    assert not any(v for v in eng.rollout_path().values())           # before the first rollout call: nothing
     eng.rollout_random(20, *ring, reset_every=1000)
     torch.cuda.synchronize()
     path = eng.rollout_path()
     want_aql = os.environ.get("SSD_AQL", "1") != "0"
     want_coh = want_aql and os.environ.get("SSD_AQL_COHERENT", "1") != "0"
     want_split = want_coh and os.environ.get("SSD_AQL_SPLIT", "1") != "0"
-    assert path == {"aql": want_aql, "coherent": want_coh, "split": want_split, "fused": False, "pipelined": False, "chains": 2}, path
-    eng.rollout_random(3, *ring, reset_every=1000, step0=20)              # (short calls are not split)
+    core = {k: path[k] for k in ("aql", "coherent", "split", "fused", "sync", "chains")}
+    assert core == {"aql": want_aql, "coherent": want_coh, "split": want_split, "fused": False, "sync": False, "chains": 2}, path
+    assert not path["queue_dropped"] and (path["pool"] >= 2 or not want_aql), path   # (a plain process: the pool's two queues pass their probe)
+    # the path must not be named before it is certain -- more argument blocks than the library keeps go through
+    # hipLaunchKernel, and ssd_rollout_path says so
+    big_rew = torch.empty((1100,) + tuple(ring[1].shape[1:]), dtype=torch.int32, device="cuda")
+    eng.rollout_random(2, None, big_rew, None, reset_every=1000, step0=20)   # 2 chains x 1100 slots > 2048 blocks
+    assert eng.rollout_path()["aql"] is False and eng.rollout_path()["chains"] == 2, eng.rollout_path()
+    eng.rollout_random(20, *ring, reset_every=1000, step0=22)
+    assert eng.rollout_path()["aql"] == want_aql
+    eng.rollout_random(3, *ring, reset_every=1000, step0=42)              # (short calls are not split)
     assert eng.rollout_path()["split"] is False and eng.rollout_path()["aql"] == want_aql
-    eng.rollout_random(8, *ring, reset_every=1000, step0=23, fused=True)
+    eng.rollout_random(8, *ring, reset_every=1000, step0=45, fused=True)
     assert eng.rollout_path()["fused"] and not eng.rollout_path()["aql"]
     torch.cuda.synchronize()
     assert eng.status() == 0
 
 
-@pytest.mark.parametrize("hwq,chains", [(None, 3), ("2", 2), ("3", 1)])
+@pytest.mark.parametrize("hwq,chains", [(None, 2), ("1", 3), ("2", 2), ("3", 1)])
 def test_automatic_chains_stay_within_the_queue_budget(hwq, chains):
     """A process has about four hardware queues before the device time-slices them; the HIP runtime takes up to GPU_MAX_HW_QUEUES of
-    them.  The library's pool of dispatch queues is what is left when the process sets that variable (3 otherwise), and an
-    automatic chain count never exceeds the pool: 8192 envs are stepped as 3 chains, as 2 next to a runtime held to 2 queues (what
-    bench.py does as a rank of a process group), as 1 next to one held to 3 -- always through the library's own queues, and with the
-    oracle's results.  (A process of its own each: both libraries read the variable once.)"""
+    them.  The library's pool of dispatch queues is what is left when the process sets that variable (2 otherwise: the rule in
+    include/ssd.h), and an automatic chain count never exceeds the pool: 8192 envs are stepped as 2 chains by default, as 3 next to a
+    runtime held to 1 queue, as 2 next to one held to 2 (what bench.py does as a rank of a process group), as 1 next to one held to
+    3 -- always through the library's own queues, and with the oracle's results.  (A process of its own each: both libraries read the variable once.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -333,13 +338,13 @@ def test_automatic_chains_stay_within_the_queue_budget(hwq, chains):
     assert r.returncode == 0 and ("PATH True %d" % chains) in out, out[-1500:]
 
 
-@pytest.mark.parametrize("mode", ["calls", "chains", "chains3", "fused", "pipelined"])
+@pytest.mark.parametrize("mode", ["calls", "chains", "chains3", "fused", "actions", "actions_fused"])
 @pytest.mark.parametrize("cfg", ["harvest25x38", "cleanup48x36"])
 def test_enlarged_maps_at_their_bench_sizes(cfg, mode):
     """BASELINE.json's enlarged configurations at the sizes bench.py reports them: Harvest 25x38, 5 agents, 4096 envs (the
     label of configs[1]) and Cleanup 48x36, 10 agents, 2048 envs (configs[4]'s per-GPU share: the LDS-tile stress -- the 64 KB
     clamp of envs_per_block(), the 8 list registers, the pipelining capacity rule), 32 steps with a reset inside, stepped call
-    by call, as rollout chains, as the fused kernel and with pipelined launches where the library honours the request."""
+    by call, as rollout chains (device-drawn and caller-supplied actions), and as the fused kernel."""
     import torch
     if cfg == "harvest25x38":
         game, amap, E, N = K.GAME_HARVEST, K.harvest_map_25x38(), 4096, 5
@@ -363,8 +368,8 @@ def test_enlarged_maps_at_their_bench_sizes(cfg, mode):
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
         assert eng.status() == 0
         return
-    kw = dict(fused=(mode == "fused"), pipelined=(mode == "pipelined"))
-    _rollout_vs_oracle(game, amap, E, N, seed=4, steps=32, step0=3, every=13, ring=2, chains={"chains3": 3}.get(mode, 2 if mode == "chains" else 1), **kw)
+    kw = dict(fused=mode.endswith("fused"), actions=mode.startswith("actions"))
+    _rollout_vs_oracle(game, amap, E, N, seed=4, steps=32, step0=3, every=13, ring=2, chains={"chains3": 3, "chains": 2, "actions": 2}.get(mode, 1), **kw)
 
 
 def test_fuzz_slice_against_the_oracle():

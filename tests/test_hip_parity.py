@@ -527,27 +527,35 @@ def test_fused_rollout_specialisations(cfg):
 
 
 @pytest.mark.parametrize("game", [K.GAME_HARVEST, K.GAME_CLEANUP])
-@pytest.mark.parametrize("chains", [1, 2])
-def test_pipelined_rollout_matches_the_oracle(game, chains):
-    """SSD_ROLLOUT_PIPELINED: step launches alternate between two streams and each env's wave waits for that env's previous
-    step through a counter in device memory instead of stream order.  Same results as the oracle stepped call by call:
-    every ring slot, across resets in the middle of a call and across two calls; no wave ever gives up waiting."""
+@pytest.mark.parametrize("mode", ["chain1", "chain2", "fused"])
+def test_rollout_actions_matches_the_oracle(game, mode):
+    """ssd_rollout_actions: the rollout call with CALLER-SUPPLIED actions (what the reference's callers do per step,
+    visuallizer_rllib.py:121-153 -> map_env.py:152-212), through every dispatch form -- the library's own queues with one and two
+    chains (split rendering from 4 steps on), the fused kernel.  Action ring and output ring of different lengths (argument blocks
+    per residue of lcm(3, 4) = 12), absent agents (-1), resets in the middle of a call, calls of 1 / 2 / many steps; the same
+    buffers again (cached argument set) and other buffers (a new set).  Oracle stepped call by call with the same actions."""
     import torch
-    E, N, ring, every = 300, 5, 3, 11
+    E, N, ring, aring, every = 300, 5, 3, 4, 11
+    na = 8 if game == K.GAME_HARVEST else 9
     eng = VecEngine(game, None, num_envs=E, num_agents=N, seed=5)
     ora = pyoracle.Oracle(game, K.HARVEST_MAP if game == K.GAME_HARVEST else K.CLEANUP_MAP, E, N, G.default_lut(), seed=5)
     obs = torch.zeros((ring, E, N, 15, 15, 3), dtype=torch.uint8, device="cuda")
     rew = torch.zeros((ring, E, N), dtype=torch.int32, device="cuda")
     done = torch.zeros((ring, E, N), dtype=torch.uint8, device="cuda")
-    eng.set_rollout_chains(chains)
+    acts = [torch.zeros((aring, E, N), dtype=torch.int32, device="cuda") for _ in range(2)]
+    eng.set_rollout_chains(2 if mode == "chain2" else 1)
+    rng = np.random.RandomState(17 + game)
     total = 0
-    for n in (25, 1, 38):                                       # (a single step is not pipelined: nothing to overlap)
-        eng.rollout_random(n, obs, rew, done, reset_every=every, step0=total, pipelined=True)
+    for call, n in enumerate((4, 1, 2, 4, 3, 4)):               # (at most `aring` steps per call: a slot is read once per call)
+        a_host = rng.randint(-1, na, size=(aring, E, N)).astype(np.int32)
+        buf = acts[call % 2] if call >= 3 else acts[0]
+        buf.copy_(torch.from_numpy(a_host))
+        eng.rollout_actions(buf, n, obs, rew, done, reset_every=every, step0=total, fused=(mode == "fused"))
         want = {}
         for k in range(total, total + n):
             if k % every == 0:
                 ora.reset()
-            _, o_obs, o_rew, _ = ora.step_random()
+            o_obs, o_rew, _ = ora.step(a_host[k % aring])
             want[k] = (o_obs, o_rew)
         total += n
         got_obs, got_rew = obs.cpu().numpy(), rew.cpu().numpy()
@@ -557,17 +565,32 @@ def test_pipelined_rollout_matches_the_oracle(game, chains):
         a, b = eng.get_state(), ora.get_state()
         for key in ("world", "pos", "orient", "episode", "t"):
             np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+        path = eng.rollout_path()
+        assert path["fused"] == (mode == "fused") and path["chains"] == (2 if mode == "chain2" else 1), path
     assert eng.status() == 0
-    # afterwards the ordinary paths continue from the same state
+    # a bad action id is reported, not obeyed (KeyError in agent.action_map)
+    acts[0].fill_(na)
+    eng.rollout_actions(acts[0], 2, obs, rew, done, step0=total, fused=(mode == "fused"))
+    from sequential_social_dilemma_games_amd import _capi
+    assert eng.status() == _capi.SSD_ST_BAD_ACTION
+    o_obs, o_rew, _ = ora.step(np.full((E, N), -1, np.int32))
+    o_obs, o_rew, _ = ora.step(np.full((E, N), -1, np.int32))
+    np.testing.assert_array_equal(obs[(total + 1) % ring].cpu().numpy(), o_obs)
+    # afterwards the ordinary paths continue from the same state; a plain step through the chains (SSD_STEP_CHAINS) too
+    a1 = rng.randint(0, na, size=(E, N)).astype(np.int32)
+    o2, r2, _ = eng.step(torch.from_numpy(a1).cuda(), chains=True)
+    o_obs, o_rew, _ = ora.step(a1)
+    np.testing.assert_array_equal(o2.cpu().numpy(), o_obs)
+    np.testing.assert_array_equal(r2.cpu().numpy(), o_rew)
     o2, r2, _ = eng.step_random()
     _, o_obs, o_rew, _ = ora.step_random()
     np.testing.assert_array_equal(o2.cpu().numpy(), o_obs)
     np.testing.assert_array_equal(r2.cpu().numpy(), o_rew)
 
 
-def test_two_handles_asking_for_pipelined_rollouts():
-    """Only one handle per device pipelines at a time (the room-to-spare rule counts one handle's launches): a second handle
-    that asks while the first one's rollout is still in flight gets plain launches.  Either way both are bit-exact."""
+def test_two_handles_share_the_dispatch_queues():
+    """The library's dispatch queues belong to the device, not to a handle: two handles whose rollout calls are enqueued back
+    to back follow each other in them.  Both bit-exact."""
     import torch
     E, N, ring, steps = 1024, 5, 2, 60
     engs = [VecEngine(g, None, num_envs=E, num_agents=N, seed=31 + g) for g in (K.GAME_HARVEST, K.GAME_CLEANUP)]
@@ -575,9 +598,11 @@ def test_two_handles_asking_for_pipelined_rollouts():
             for g in (K.GAME_HARVEST, K.GAME_CLEANUP)]
     bufs = [(torch.zeros((ring, E, N, 15, 15, 3), dtype=torch.uint8, device="cuda"),
              torch.zeros((ring, E, N), dtype=torch.int32, device="cuda")) for _ in engs]
+    for eng in engs:
+        eng.set_rollout_chains(2)
     for rep in range(2):
         for eng, (obs, rew) in zip(engs, bufs):                  # enqueued back to back: the second call finds the first in flight
-            eng.rollout_random(steps, obs, rew, None, reset_every=25, step0=rep * steps, pipelined=True)
+            eng.rollout_random(steps, obs, rew, None, reset_every=25, step0=rep * steps)
         for eng, ora, (obs, rew) in zip(engs, oras, bufs):
             for k in range(rep * steps, (rep + 1) * steps):
                 if k % 25 == 0:

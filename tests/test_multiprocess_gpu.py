@@ -1,9 +1,9 @@
-"""Several PROCESSES on one GPU (the closest a one-GPU box comes to the N-rank job, and the co-tenant case of pipelined launches):
+"""Several PROCESSES on one GPU (the closest a one-GPU box comes to the N-rank job, and the co-tenant case of the dispatch queues):
   * two ranks under torch.distributed (gloo; both on cuda:0) each step their shard of a 4096-env batch with the HIP engine
     (env_index_base 0 / 2048) and all-gather it: equal to one engine stepping all 4096 envs -- run_scripts/train_moa.py:127-128's
     workers, SURVEY.md 8e;
-  * a pipelined rollout (SSD_ROLLOUT_PIPELINED) stays bit-exact, status word 0, while another process keeps the same GPU busy
-    with plain step launches."""
+  * rollout calls through the library's own queues (device-drawn and caller-supplied actions) stay bit-exact, status word 0,
+    while another process keeps the same GPU busy with plain step launches."""
 import os
 import socket
 import subprocess
@@ -118,7 +118,30 @@ def test_bench_with_two_ranks_rehearsed_on_one_gpu():
     # both ranks' 20 steps of 4096 envs x 5 agents over the slower rank's time
     assert abs(res["value"] - 2 * 4096 * 5 * 20 / (res["ms_per_step"] * 1e-3 * 20)) < 1e-6 * res["value"]
     assert res["config"]["dispatch"].startswith("AQL packets")
+    # every rank says how its rollout was dispatched -- a rank that fell back to hipLaunchKernel must show
+    per_rank = res["config"]["dispatch_per_rank"]
+    assert len(per_rank) == 2 and all(p["aql"] and p["chains"] >= 1 for p in per_rank), per_rank
+    assert res["config"]["dispatch_fallback_ranks"] == []
     assert res["fused_rollout"]["value"] > 0 and "call_overhead_us" in res   # (two ranks share the device: no claim about its sign)
+
+
+def test_bench_line_survives_failing_legs():
+    """VERDICT r02 #1 on the real thing: the driver's command with failures injected into the fused leg, the policy-step leg, the
+    configs and the CPU baseline -- the headline comes out complete, every failed leg says so in its slot, exit status 0."""
+    import json
+    env = dict(os.environ, SSD_BENCH_FAIL_LEG="fused_rollout,policy_step,configs,cpu_baseline")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    assert res["value"] > 1e8 and res["n_gpus"] == 1 and res["roofline"]["frac"] > 0 and res["config"]["dispatch_fallback_ranks"] == []
+    for leg in ("fused_rollout", "policy_step", "configs", "cpu_baseline"):
+        assert "injected failure" in res[leg]["error"], (leg, res[leg])
+    assert "call_overhead_us" in res and "us_per_step" in res["busy_stream_call"]       # the legs that were not told to fail ran
 
 
 _LOAD_SCRIPT = r'''
@@ -141,10 +164,10 @@ print("load done", flush=True)
 
 
 @pytest.mark.parametrize("game", [K.GAME_HARVEST, K.GAME_CLEANUP])
-def test_pipelined_rollout_with_another_process_on_the_gpu(game, tmp_path):
-    """SSD_ROLLOUT_PIPELINED's waves wait for flags that another of the handle's launches publishes; its capacity rule counts
-    one process.  With a second process filling the same GPU with plain 4096-env step launches the rollout must still come out
-    bit-exact and no wave may have given up (status word 0: SSD_ST_PIPE_TIMEOUT not set)."""
+def test_rollout_chains_with_another_process_on_the_gpu(game, tmp_path):
+    """The stream-side join of a rollout call waits (bounded) for the library's queues, whose kernels share the device with
+    whatever else runs there.  With a second process filling the same GPU with plain 4096-env step launches the rollout must still
+    come out bit-exact and the wait must not have given up (status word 0: SSD_ST_WAIT_TIMEOUT not set)."""
     import torch
     from sequential_social_dilemma_games_amd.engine import VecEngine
     script = tmp_path / "load.py"
@@ -162,7 +185,7 @@ def test_pipelined_rollout_with_another_process_on_the_gpu(game, tmp_path):
         obs = torch.zeros((ring, E, N, 15, 15, 3), dtype=torch.uint8, device="cuda")
         rew = torch.zeros((ring, E, N), dtype=torch.int32, device="cuda")
         for c0 in range(0, steps, 100):                      # several calls while the other process is at work
-            eng.rollout_random(100, obs, rew, None, reset_every=every, step0=c0, pipelined=True)
+            eng.rollout_random(100, obs, rew, None, reset_every=every, step0=c0)
         torch.cuda.synchronize()
         assert load.poll() is None, "the load process ended before the rollout did: nothing was tested"
         want = {}

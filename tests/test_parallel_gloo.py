@@ -61,6 +61,15 @@ def _worker(rank, world, port, total, game, n_agents, steps, q):
         for rr in range(w):
             for k in range(4):
                 assert (got[rr, k] == 100 * k + rr).all()
+        # ... and the gather-to-root form (north_star: "gather ... only when a single batched tensor is requested")
+        got = parallel.gather_ring(dist, ring, w, r, dst=0)
+        if r == 0:
+            assert tuple(got.shape) == (w, 4, count, 3)
+            for rr in range(w):
+                for k in range(4):
+                    assert (got[rr, k] == 100 * k + rr).all()
+        else:
+            assert got is None
     dist.barrier()
     if r == 0:
         q.put(out)

@@ -1,0 +1,95 @@
+"""The hardware-queue cliff: a process has about four hardware queues before the device time-slices them, and past
+that EVERY kernel launch of the process takes ~30 us.  The library's dispatch queues count against that budget, so every queue of its
+pool is probed when it is created (csrc/ssd_aql.hip: a burst of dispatches on it, a burst of HIP launches, against the figures
+from before the pool grew) and destroyed again if its arrival slows the process down.
+
+Here the engine runs inside a process that ALREADY keeps three torch side streams (+ the default stream) busy -- the HIP runtime's
+four hardware queues are all in use.  Whatever the library settles on: (i) the rollout is bit-exact, (ii) the process's plain
+kernel-launch cost after the first rollout is what it was before (within 20 %), (iii) the chain count stays within the pool the
+probe left, and the path says what happened.  A process of its own (queues are per process)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_CODE = r'''
+import sys, time, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np, torch
+import golden_util as G
+from oracle import pyoracle
+from sequential_social_dilemma_games_amd import constants as K
+from sequential_social_dilemma_games_amd.engine import VecEngine
+
+side = [torch.cuda.Stream() for _ in range(3)]
+bufs = [torch.zeros(1 << 22, device="cuda") for _ in side]
+def keep_busy(n):
+    for s, t in zip(side, bufs):
+        with torch.cuda.stream(s):
+            for _ in range(n):
+                t.add_(1.0)
+y = torch.zeros(256, device="cuda")
+def launch_cost():                       # us per plain launch of the process: a burst on the default stream, side streams at work
+    vals = []
+    for _ in range(7):
+        keep_busy(50)
+        torch.cuda.synchronize()
+        keep_busy(400)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            y.add_(1.0)
+        torch.cuda.current_stream().synchronize()
+        vals.append((time.perf_counter() - t0) * 1e6 / 200)
+        torch.cuda.synchronize()
+    return float(np.median(vals))
+keep_busy(100); torch.cuda.synchronize()
+before = launch_cost()
+E, N = 4096, 5
+eng = VecEngine(K.GAME_HARVEST, None, num_envs=E, num_agents=N, seed=3)
+ora = pyoracle.Oracle(K.GAME_HARVEST, K.HARVEST_MAP, E, N, G.default_lut(), seed=3)
+out = eng.alloc_outputs(); ring = tuple(t.unsqueeze(0) for t in out)
+keep_busy(300)
+eng.rollout_random(12, *ring, reset_every=1000, step0=0)       # first rollout: the pool's queues are created and probed here
+torch.cuda.synchronize()
+ora.reset()
+for k in range(12):
+    _, o_obs, o_rew, _ = ora.step_random(want_obs=(k == 11))
+assert np.array_equal(ring[1][0].cpu().numpy(), o_rew) and np.array_equal(ring[0][0].cpu().numpy(), o_obs), "rollout differs from the oracle"
+path = eng.rollout_path()
+after = launch_cost()
+keep_busy(300)
+eng.rollout_random(20, *ring, reset_every=1000, step0=12)      # and again, with the pool settled
+torch.cuda.synchronize()
+for k in range(20):
+    _, o_obs, o_rew, _ = ora.step_random(want_obs=(k == 19))
+assert np.array_equal(ring[1][0].cpu().numpy(), o_rew) and np.array_equal(ring[0][0].cpu().numpy(), o_obs), "second rollout differs from the oracle"
+path2 = eng.rollout_path()
+assert eng.status() == 0
+print("RESULT " + json.dumps({"before_us": before, "after_us": after, "path": path, "path2": path2}))
+'''
+
+
+def test_engine_in_a_process_with_busy_streams():
+    import json
+    env = dict(os.environ, SSD_AQL_VERBOSE="1")
+    for k in ("GPU_MAX_HW_QUEUES", "SSD_AQL_QUEUES", "SSD_ROLLOUT_CHAINS", "SSD_AQL", "SSD_LIB_PATH"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", _CODE % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "RESULT " in out, out[-3000:]
+    res = json.loads(out[out.index("RESULT ") + 7:].splitlines()[0])
+    print(out[-2500:])
+    # (ii) the process's own launches cost what they cost before the library came
+    assert res["after_us"] <= 1.2 * res["before_us"] + 0.5, res
+    # (iii) chains within the pool the probe left; a dropped queue is reported; without queues of its own: HIP streams
+    for p in (res["path"], res["path2"]):
+        assert p["chains"] >= 1
+        if p["aql"]:
+            assert p["chains"] <= p["pool"], p
+    if res["path2"]["queue_dropped"]:
+        assert res["path2"]["pool"] < 2 or not res["path2"]["aql"], res

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Long-run parity soak (GPU box): E envs, T random-action steps with a reset every 1000 steps; every K steps the
 engine's full state (world, positions, orientations, counters) and the step's observations / rewards are compared
-with the C oracle's.  python tools/soak_parity.py [harvest|cleanup|harvest25x38|cleanup48x36] [E] [T] [K] [step|chains|fused]
+with the C oracle's.  python tools/soak_parity.py [harvest|cleanup|harvest25x38|cleanup48x36] [E] [T] [K] [step|chains|fused|actions|actions_fused]
 (step: one step_random call per step; chains: ssd_rollout_random with 2 chains between checkpoints; fused: the rollout
-kernel, one launch between checkpoints)"""
+kernel, one launch between checkpoints; actions / actions_fused: the same two with CALLER-SUPPLIED actions, ssd_rollout_actions,
+a fresh random action tensor per chunk and the oracle stepped with the same actions).  The first line of the output says which
+library ran under which SSD_* settings (tools/_label.py).  SOAK_EXPECT_PATH=sync|aql: the dispatch path the calls must report."""
 import os
 import sys
 import time
@@ -17,9 +19,12 @@ import golden_util as G  # noqa: E402
 from oracle import pyoracle  # noqa: E402
 from sequential_social_dilemma_games_amd import constants as K  # noqa: E402
 from sequential_social_dilemma_games_amd.engine import VecEngine  # noqa: E402
+sys.path.insert(0, os.path.join(REPO, "tools"))
+from _label import label  # noqa: E402
 
 
 def main():
+    label("soak_parity " + " ".join(sys.argv[1:]))
     which = sys.argv[1] if len(sys.argv) > 1 else "harvest"   # harvest | cleanup | harvest25x38 | cleanup48x36 (the enlarged maps, 5 / 10 agents)
     game = K.GAME_CLEANUP if which.startswith("cleanup") else K.GAME_HARVEST
     E = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
@@ -46,7 +51,12 @@ def main():
     ring = tuple(t.unsqueeze(0) for t in out) if R == 1 else tuple(torch.zeros((R,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in out)
     if how != "step":
         assert 1000 % Kc == 0
-        eng.set_rollout_chains(2 if how == "chains" else 1)
+        eng.set_rollout_chains(2 if how in ("chains", "actions") else 1)
+    use_actions = how.startswith("actions")
+    na = 8 if game == K.GAME_HARVEST else 9
+    rng = np.random.RandomState(99)
+    a_dev = torch.zeros((Kc, E, n_agents), dtype=torch.int32, device="cuda") if use_actions else None
+    expect = os.environ.get("SOAK_EXPECT_PATH")
     for s in range(T):
         if s and s % 1000 == 0:
             ora.reset()
@@ -56,10 +66,20 @@ def main():
         if how == "step":
             obs, rew, _ = eng.step_random(out=out)
         elif s % Kc == 0:                                      # the Kc steps up to the next checkpoint in one library call
-            eng.rollout_random(Kc, *ring, reset_every=1000, step0=s, fused=(how == "fused"))
+            if use_actions:
+                a_host = rng.randint(-1, na, size=(Kc, E, n_agents)).astype(np.int32)
+                a_dev.copy_(torch.from_numpy(a_host))
+                eng.rollout_actions(a_dev, Kc, *ring, reset_every=1000, step0=s, fused=how.endswith("fused"))
+            else:
+                eng.rollout_random(Kc, *ring, reset_every=1000, step0=s, fused=(how == "fused"))
+            if expect:
+                assert eng.rollout_path()[expect], eng.rollout_path()
             last = (s + Kc - 1) % R
             obs, rew = ring[0][last], ring[1][last]
-        _, o_obs, o_rew, _ = ora.step_random(want_obs=want_obs)
+        if use_actions:
+            o_obs, o_rew, _ = ora.step(a_host[s % Kc])
+        else:
+            _, o_obs, o_rew, _ = ora.step_random(want_obs=want_obs)
         if want_obs:
             r = rew.cpu().numpy()
             assert np.array_equal(r, o_rew), "rewards differ at step %d" % s

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r02_traffic.json from the rocprofv3 summaries tools/profile_r02.sh leaves in gpurun_out/r02_prof/<tag>/:
+"""profiles/<round>_traffic.json (python tools/traffic_json.py r03) from the rocprofv3 summaries tools/profile_<round>.sh leaves in gpurun_out/<round>_prof/<tag>/:
 HBM bytes per step = (2 x FETCH_SIZE + WRITE_SIZE) KiB of the step kernel's dispatches (separate --pmc passes; FETCH_SIZE doubled per
 the gfx950 correction of MI355X_MICROARCH.md) x the launches of one step, next to the algorithmic bytes of SURVEY.md 8d; plus
 the step kernel's average duration under --kernel-trace.  Also copies the per-workload summaries into profiles/."""
@@ -14,12 +14,13 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from sequential_social_dilemma_games_amd import config as cfgmod  # noqa: E402
 
-SRC = os.path.join(REPO, "gpurun_out", "r02_prof")
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SRC = os.path.join(REPO, "gpurun_out", "%s_prof" % ROUND)
 DST = os.path.join(REPO, "profiles")
 WORK = {   # tag -> (H, W, N, E, chains, f32)
     "harvest_16x38_n5_e4096": (16, 38, 5, 4096, 2, False), "cleanup_25x18_n5_e4096": (25, 18, 5, 4096, 2, False),
     "harvest_25x38_n5_e4096": (25, 38, 5, 4096, 2, False), "cleanup_48x36_n10_e2048": (48, 36, 10, 2048, 2, False),
-    "harvest_16x38_n5_e4096_f32": (16, 38, 5, 4096, 2, True), "harvest_16x38_n5_e2048_pipelined": (16, 38, 5, 2048, 1, False),
+    "harvest_16x38_n5_e4096_f32": (16, 38, 5, 4096, 2, True),
 }
 
 
@@ -38,18 +39,18 @@ def main():
         ent = {"launches_per_step": chains}
         ks = os.path.join(d, "kernel_stats.csv")
         if os.path.exists(ks):
-            shutil.copy(ks, os.path.join(DST, "r02_%s_kernel_stats.csv" % tag))
+            shutil.copy(ks, os.path.join(DST, "%s_%s_kernel_stats.csv" % (ROUND, tag)))
             rows = [r for r in csv.DictReader(open(ks)) if step_kernel(r["Name"])]
             if rows:
                 r = max(rows, key=lambda r: int(r["Calls"]))
                 ent["rocprof_avg_kernel_us"] = float(r["AverageNs"]) / 1e3
                 ent["rocprof_kernel"] = r["Name"].split("(")[0]
                 ent["rocprof_calls"] = int(r["Calls"])
-                ent["rocprof_source"] = ("profiles/r02_%s_kernel_stats.csv: per launch of %d envs under rocprofv3 --kernel-trace (tracing adds "
-                                         "per-dispatch overhead; not the unprofiled step time)" % (tag, E // chains))
+                ent["rocprof_source"] = ("profiles/%s_%s_kernel_stats.csv: per launch of %d envs under rocprofv3 --kernel-trace (tracing adds "
+                                         "per-dispatch overhead; not the unprofiled step time)" % (ROUND, tag, E // chains))
         ps = os.path.join(d, "pmc_summary.txt")
         if os.path.exists(ps) and os.path.getsize(ps):
-            shutil.copy(ps, os.path.join(DST, "r02_%s_pmc_summary.txt" % tag))
+            shutil.copy(ps, os.path.join(DST, "%s_%s_pmc_summary.txt" % (ROUND, tag)))
             vals = {}
             for line in open(ps):
                 m = re.match(r"(.*?)\s+(\S+)\s+avg/dispatch\s+([\d.]+)\s+\(n=(\d+)\)", line)
@@ -63,9 +64,10 @@ def main():
                 ent.update(fetch_size_kib_per_launch=f, write_size_kib_per_launch=w,
                            hbm_bytes_per_launch=int(round((2 * f + w) * 1024 * chains)), algorithmic_bytes_per_step=alg * E)
                 ent["ratio"] = round(ent["hbm_bytes_per_launch"] / ent["algorithmic_bytes_per_step"], 3)
-                ent["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_r02.sh, SSD_AQL_SYNC=1); FETCH_SIZE doubled "
-                               "per the gfx950 correction (MI355X_MICROARCH.md, HBM).  bench.py steps the envs as %d concurrent launch(es) per step; the "
-                               "counters are per launch, hbm_bytes_per_launch here is the sum over the launches of one step." % chains)
+                ent["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_%s.sh; host-side waits, chosen by the "
+                               "library itself under a tool); FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM).  bench.py steps the "
+                               "envs as %d concurrent launch(es) per step; the counters are per launch, hbm_bytes_per_launch here is the sum over the "
+                               "launches of one step." % (ROUND, chains))
         bt = os.path.join(d, "bench_under_trace.json")
         if os.path.exists(bt) and os.path.getsize(bt):
             try:
@@ -73,7 +75,7 @@ def main():
             except Exception:
                 pass
         out[tag] = ent
-    json.dump(out, open(os.path.join(DST, "r02_traffic.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(DST, "%s_traffic.json" % ROUND), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
