@@ -181,12 +181,17 @@ int ssd_rollout_path(const ssd_env *env);
  * of the process -- the host application's too -- takes ~30 us.  The HIP runtime takes up to GPU_MAX_HW_QUEUES of them (default 4,
  * one per stream in use), RCCL one more stream.  So: the library's pool holds SSD_AQL_QUEUES queues (1..3) if that is set; else
  * 4 - GPU_MAX_HW_QUEUES if the process sets that variable for the HIP runtime (at least 1); else 2.  And whatever the rule says,
- * every queue is PROBED when it is created (first rollout call that needs it; the device is synchronised once): a burst of one-wave
- * dispatches on the new queue and a burst of HIP launches on the null stream, against the figures from before the pool grew.  A
- * queue whose arrival makes either burst more than 2.5 x (+ 20 us) slower is destroyed again and the pool stays at the size that
- * was fine for the life of the process (SSD_PATH_QUEUE_DROPPED, bits 12..14 of ssd_rollout_path); a call that asked for more
- * chains goes through HIP streams.  Streams the host application creates LATER are not seen by the probe: an application that
- * knows it will hold many should set SSD_AQL_QUEUES=1 or SSD_AQL=0.
+ * every queue is PROBED when it is created (first rollout call that needs it; the device is synchronised once).  The cliff is about
+ * queues that are ACTIVE at the same time, so the probe is a rollout in miniature: 16 dependent one-wave dispatches on every queue
+ * of the pool at once, joined through the null stream the way a rollout call is joined, timed against the pool's first queue
+ * alone (MI355X: ~50 us with a hardware queue slot each, ~140 us when time-sliced); and a burst of HIP launches against its figure
+ * from before the pool existed.  A queue whose arrival makes the concurrent burst more than 1.6 x (+ 10 us) slower, or the HIP burst
+ * more than 2.5 x (+ 20 us), is destroyed again and the pool stays at the size that was fine for the life of the process
+ * (SSD_PATH_QUEUE_DROPPED, bits 12..14 of ssd_rollout_path); an automatic chain count follows the smaller pool.  If already the
+ * FIRST queue's burst takes more than 100 us, the process is past the cliff without the library (a host application with four
+ * busy streams): the library then holds no queue at all and an automatic chain count is 1 -- the launches go to the caller's own
+ * stream.  Streams the host application starts using LATER are not seen by the probe: an application that knows it will hold
+ * many should set SSD_AQL_QUEUES=1 or SSD_AQL=0.
  *
  * ENVIRONMENT (read once per process; these are all the variables the product library reads):
  *   SSD_AQL=0            no dispatch queues of the library's own: every launch through hipLaunchKernel

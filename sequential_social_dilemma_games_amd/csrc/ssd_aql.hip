@@ -65,7 +65,8 @@ namespace {
     X(hsa_executable_freeze) X(hsa_executable_get_symbol_by_name) X(hsa_executable_symbol_get_info) X(hsa_status_string)           \
     X(hsa_signal_wait_scacquire)
 
-constexpr int kPoolQueues = 3;
+constexpr int kPoolQueues = 3;                              // what the product ever holds per device
+constexpr int kPoolSlots = 8;                               // (test-hook build: SSD_AQL_POOL_MAX lifts the limit up to here, to find the cliff)
 #ifndef SSD_ARCH
 #define SSD_ARCH "gfx950"                                   // (the Makefile passes its ARCH)
 #endif
@@ -86,15 +87,16 @@ struct DeviceCtx {
     std::unordered_map<const void *, Kernel> kernels;     // by host stub
     std::string why;                                      // why not ok
     // the device's dispatch queues, shared by every handle on it (queues are scarce: see queue_create), and what they share
-    struct Queue *pool[kPoolQueues] = {};
+    struct Queue *pool[kPoolSlots] = {};
     std::mutex enqueue_mu;                                // one rollout call writes packets at a time
     uint32_t *abort_host = nullptr;                       // host memory (device-mapped): a queue of the device reported an error
     void *abort_dev = nullptr;
     // the probe (probe_pool_queue): what a burst of HIP launches / of dispatches on a pool queue cost before the pool grew
     unsigned long long *probe_counter = nullptr;          // device memory the probe's one-wave dispatches bump
     void *probe_kernarg = nullptr;
+    unsigned long long probe_count = 0;                   // value probe_counter reaches when every probe dispatch so far has run
     double hip_burst_base_us = 0, hip_burst_last_us = 0, q_burst_base_us = 0, q_burst_last_us = 0;
-    int pool_cap = kPoolQueues;                           // shrinks when a new queue fails its probe
+    int pool_cap = kPoolSlots;                            // shrinks when a new queue fails its probe
     int dropped = 0;                                      // queues destroyed again by the probe
     const char *matched_by = "";                          // how the HSA agent was matched to the HIP device
 };
@@ -251,6 +253,31 @@ DeviceCtx *device_ctx(int device) {
 
 bool available(int device) { return device_ctx(device) != nullptr; }
 
+// Is a profiling / tracing tool attached to this process?  Such tools may run kernels ONE AT A TIME (rocprofv3 --pmc does): a
+// kernel that waits for another queue's kernel -- the stream-side wait of the join, the chains' wait for the fork -- would then
+// never end.  With a tool attached the rollout calls therefore use host-side waits ("sync mode": the call itself waits for the
+// stream before and for the chains after; no kernel waits for another).  SSD_AQL_SYNC=1 / 0 forces / forbids that.
+// What counts as attached: the variables the ROCm tools are started with, or their libraries already loaded in the process.
+int tool_attached_now() {
+    static const char *const vars[] = {"ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROF_COUNTER_COLLECTION", "ROCPROFILER_METRICS_PATH",
+                                       "ROCPROF_ATT_LIBRARY_PATH"};
+    for (const char *n : vars) { const char *v = getenv(n); if (v && *v) return 1; }
+    if (const char *pl = getenv("LD_PRELOAD")) { if (std::strstr(pl, "rocprof") || std::strstr(pl, "roctracer") || std::strstr(pl, "omnitrace") || std::strstr(pl, "rocsys")) return 1; }
+    static const char *const libs[] = {"librocprofiler-sdk.so.1", "librocprofiler-sdk.so", "librocprofiler-sdk-tool.so", "librocprofiler64.so.2",
+                                       "librocprofiler64.so.1", "librocprofiler64.so"};
+    for (const char *l : libs)
+        if (void *h = dlopen(l, RTLD_LAZY | RTLD_NOLOAD)) { dlclose(h); return 1; }
+    return 0;
+}
+bool sync_mode() {
+    static const bool v = [] {
+        const char *e = getenv("SSD_AQL_SYNC");
+        if (e && *e) return atoi(e) != 0;
+        return tool_attached_now() != 0;
+    }();
+    return v;
+}
+
 const char *why_not(int device) {
     if (device < 0 || device >= 64) return "bad device";
     return g_dev[device].why.c_str();
@@ -357,25 +384,37 @@ static int pool_limit() {
         int v = 2;
         if (const char *h = getenv("GPU_MAX_HW_QUEUES")) { const int hq = atoi(h); if (hq >= 1) v = 4 - hq; }
         if (const char *o = getenv("SSD_AQL_QUEUES")) v = atoi(o);
-        return v < 1 ? 1 : v > kPoolQueues ? kPoolQueues : v;
+        int top = SSD_HOOK("SSD_AQL_POOL_MAX", kPoolQueues);
+        top = top < 1 ? 1 : top > kPoolSlots ? kPoolSlots : top;
+        return v < 1 ? 1 : v > top ? top : v;
     }();
     return n;
 }
 int pool_size(int device) {
     if (device < 0 || device >= 64) return 1;
-    const int cap = g_dev[device].pool_cap < pool_limit() ? g_dev[device].pool_cap : pool_limit();
-    return cap < 1 ? 1 : cap;
+    return g_dev[device].pool_cap < pool_limit() ? g_dev[device].pool_cap : pool_limit();      // (0: not even one queue fits)
 }
+bool over_the_cliff(int device) { return device >= 0 && device < 64 && g_dev[device].pool_cap == 0; }
 
 static double now_us() {
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-// A burst of one-wave dispatches (barrier bit: one after the other) on Q, host-waited; microseconds, < 0 on failure.
-static double queue_burst_us(DeviceCtx *c, Queue *Q, int n) {
-    if (!Q->done_signal.handle || !c->probe_kernarg) return -1;
+// A burst on ALL of `qs` at once -- n one-wave dispatches each (barrier bit: one after the other within a queue), interleaved
+// so that every queue has work from the start -- joined the way a rollout call is joined: a one-wave kernel on the null stream
+// polls the counter the dispatches bump.  Microseconds from the first packet to the stream's completion; < 0 on failure.
+// This is the situation the cliff is about: the device runs about FOUR queues at a time (one per pipe of the command
+// processor's compute micro-engine); a fifth ACTIVE queue is time-sliced against the others, and a rollout whose chains are so
+// sliced takes twice as long (measured, 6144 envs: 3 chains 6.7 us per step, 4 chains 12.2 - 13.5, 5: 15, 8: 27 - 37 -- with the
+// joining kernel's stream that is 4, 5, 6, 9 active queues; idle queues cost nothing, and a burst on ONE queue shows nothing).
+static double concurrent_burst_us(DeviceCtx *c, Queue *const *qs, int nq, int n) {
+    if (!c->probe_kernarg || !c->probe_counter) return -1;
     const double t0 = now_us();
-    for (int i = 0; i < n - 1; ++i) dispatch(Q, Q->flag_kernel, 1, 64, 0, c->probe_kernarg, true, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE);
-    if (!join_and_wait(Q, c->probe_kernarg)) return -1;
+    for (int k = 0; k < n; ++k)
+        for (int i = 0; i < nq; ++i) dispatch(qs[i], qs[i]->flag_kernel, 1, 64, 0, c->probe_kernarg, true, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE);
+    for (int i = 0; i < nq; ++i) ring(qs[i]);
+    c->probe_count += (unsigned long long)nq * (unsigned long long)n;
+    launch_wait_counter_kernel(c->probe_counter, c->probe_count, static_cast<const uint32_t *>(c->abort_dev), 100000000ull /* 1 s */, nullptr, nullptr);
+    if (hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipGetLastError(); return -1; }
     return now_us() - t0;
 }
 // A burst of one-wave HIP launches on the null stream + synchronize; microseconds, < 0 on failure.
@@ -388,33 +427,41 @@ static double hip_burst_us(int n) {
     return now_us() - t0;
 }
 // THE PROBE.  Called with the device idle (the first rollout call of a handle synchronises anyway).  Before the pool's first queue
-// exists it records what a burst of HIP launches costs; after every new queue it measures that burst again and a burst of dispatches
-// on the new queue (against the first queue's own figure).  Past the cliff BOTH are an order of magnitude off (every dispatch waits
-// for its queue's time slice), so the thresholds need no tuning: 2.5 x the base figure plus 20 us (medians of 3 bursts of 16).
-// Returns false when the new queue must go.
+// exists it records what a burst of HIP launches costs.  After every new queue: (a) the concurrent burst above on the whole pool
+// including the new queue, against the figure of the pool's first queue alone; (b) the HIP burst again.  The new queue must go
+// when (a) exceeds 1.6 x the first queue's figure + 10 us (concurrent chains would be time-sliced: the chains it would carry are
+// better off in fewer queues), or when (b) exceeds 2.5 x its base + 20 us (the process's own launches suffer); the first queue
+// itself when its burst exceeds 100 us -- an MI355X calibration: 16 dependent one-wave dispatches + the join take 48 - 56 us on a
+// queue that has a pipe to itself and 138 - 145 us on one that is time-sliced (gpurun_out/r03c/queue_probe3.txt) -- i.e. the
+// process is past the cliff before the library came (a host application with four busy streams): then the library holds no queue
+// at all and steps on the caller's own stream.
+// Medians of 3 bursts of 16.  Returns false when the new queue must go.
 static constexpr int kBurst = 16, kBurstReps = 3;
-static double median3(double (*f)(DeviceCtx *, Queue *), DeviceCtx *c, Queue *Q) {
-    double v[kBurstReps];
-    for (double &x : v) x = f(c, Q);
-    std::sort(v, v + kBurstReps);
-    return v[0] < 0 ? -1 : v[kBurstReps / 2];
-}
 static bool probe_pool_queue(DeviceCtx *c, Queue *Q, int index) {
     static const bool probe_on = SSD_HOOK("SSD_AQL_PROBE", 1) != 0;
     if (!probe_on) return true;
-    auto hipb = [](DeviceCtx *, Queue *) { return hip_burst_us(kBurst); };
-    auto qb = [](DeviceCtx *cc, Queue *q) { return queue_burst_us(cc, q, kBurst); };
-    (void)queue_burst_us(c, Q, 2);                        // (first dispatches of a new queue: not timed)
-    const double q_us = median3(qb, c, Q), h_us = median3(hipb, c, nullptr);
+    // (a profiling tool is attached: it may run kernels one at a time -- the burst's waiting kernel would sit out its time bound --
+    // and its timings say nothing about the unprofiled process: no probe, the rule's pool size stands)
+    if (sync_mode()) { say("probe skipped: a profiling tool is attached (host-side waits)"); return true; }
+    Queue *qs[kPoolSlots];
+    int nq = 0;
+    for (int i = 0; i < index && i < kPoolSlots - 1; ++i) if (c->pool[i]) qs[nq++] = c->pool[i];
+    qs[nq++] = Q;
+    (void)concurrent_burst_us(c, qs, nq, 2);              // (first dispatches of a new queue: not timed)
+    double qv[kBurstReps], hv[kBurstReps];
+    for (double &x : qv) x = concurrent_burst_us(c, qs, nq, kBurst);
+    for (double &x : hv) x = hip_burst_us(kBurst);
+    std::sort(qv, qv + kBurstReps); std::sort(hv, hv + kBurstReps);
+    const double q_us = qv[0] < 0 ? -1 : qv[kBurstReps / 2], h_us = hv[0] < 0 ? -1 : hv[kBurstReps / 2];
     c->q_burst_last_us = q_us; c->hip_burst_last_us = h_us;
     if (index == 0) c->q_burst_base_us = q_us;
-    char msg[256];
-    snprintf(msg, sizeof msg, "probe: queue %d: %d dispatches %.1f us (first queue %.1f), %d HIP launches %.1f us (before the pool %.1f)", index, kBurst,
-             q_us, c->q_burst_base_us, kBurst, h_us, c->hip_burst_base_us);
+    char msg[320];
+    snprintf(msg, sizeof msg, "probe: %d queue(s) at once, %d dispatches each: %.1f us (the first queue alone %.1f); %d HIP launches %.1f us (before the pool %.1f)",
+             nq, kBurst, q_us, c->q_burst_base_us, kBurst, h_us, c->hip_burst_base_us);
     say(msg);
     if (q_us < 0 || h_us < 0 || c->hip_burst_base_us <= 0) return true;           // (no figures: no verdict)
     const bool hip_slow = h_us > 2.5 * c->hip_burst_base_us + 20.0;
-    const bool q_slow = index > 0 && c->q_burst_base_us > 0 && q_us > 2.5 * c->q_burst_base_us + 20.0;
+    const bool q_slow = index > 0 ? (c->q_burst_base_us > 0 && q_us > 1.6 * c->q_burst_base_us + 10.0) : (q_us > 100.0);
     return !(hip_slow || q_slow);
 }
 
@@ -465,7 +512,7 @@ Queue *pool_queue(int device, int index) {
         c->dropped++;
         // (not even one queue of the library's fits beside what the process already holds: no own dispatch path on this device,
         // the rollout calls go through hipLaunchKernel)
-        if (index == 0) { c->ok = false; c->why = "the first dispatch queue already slows the process's launches down"; }
+        if (index == 0) { c->ok = false; c->why = "the process is past the hardware-queue cliff already: no dispatch queue of the library's own"; }
         return nullptr;
     }
     std::lock_guard<std::mutex> lk(g_mu);

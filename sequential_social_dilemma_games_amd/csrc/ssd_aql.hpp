@@ -12,13 +12,16 @@ struct Queue;
 
 bool available(int device);                        // HSA runtime reachable, agent matched, code object loaded (SSD_AQL=0: never)
 const char *why_not(int device);
+int tool_attached_now();                           // a profiling / tracing tool is attached to the process (evaluated afresh)
+bool sync_mode();                                  // host-side waits instead of waiting kernels: a tool is attached, or SSD_AQL_SYNC=1
 bool lookup(int device, const void *host_fn, Kernel *out);   // kernel descriptor of the instantiation behind a HIP host stub
 
 // The device's dispatch queues: a pool of at most pool_size(device) queues per device, shared by every handle on it (queues are
 // scarce: ssd_aql.hip), created -- and probed for the hardware-queue cliff -- on first use and kept for the life of the process.
 // One rollout call writes packets at a time (enqueue_mutex).
 Queue *pool_queue(int device, int index);
-int pool_size(int device);                         // what the rule of include/ssd.h allows, less what the probe turned down
+int pool_size(int device);                         // what the rule of include/ssd.h allows, less what the probe turned down (0: none fits)
+bool over_the_cliff(int device);                   // the probe turned the pool's FIRST queue down: the process holds too many active queues already
 int pool_report(int device);                       // bits for ssd_rollout_path(): pool_size << 12 | 32 if the probe dropped a queue
 void probe_figures(int device, double out[4]);     // us: HIP burst before the pool / after its last queue, queue burst first / last
 std::mutex &enqueue_mutex(int device);

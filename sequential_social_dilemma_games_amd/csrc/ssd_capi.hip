@@ -62,8 +62,13 @@ struct AqlState {
     int nq = 0;
     static constexpr int kForks = 16;
     uint64_t fork_sig[kForks] = {};
-    uint64_t fork_used[kForks][8] = {};             // index of the barrier packet that waits on the signal, per chain (+1; 0 = unused)
+    uint64_t fork_used[kForks][8] = {};             // index of the packet that waits for the fork, per chain (+1; 0 = unused)
     int fork_next = 0;
+    unsigned long long *fork_counter = nullptr;     // device memory: += 1 by a one-wave kernel on the caller's stream per forked call
+    unsigned long long forks = 0;
+    uint8_t *fork_kernarg = nullptr;                // host kernarg memory: kForks blocks of kForkBlock bytes (the chains' waiting kernel)
+    static constexpr size_t kForkBlock = 256;
+    ssd::aql::Kernel wait_kernel{};
     unsigned long long *join_counter = nullptr;     // device memory: += 1 by every chain's last packet of a call
     unsigned long long joins = 0;                   // value it reaches when everything enqueued so far is done
     void *flag_kernarg = nullptr;                   // host kernarg block: the flag kernel's argument (= join_counter)
@@ -672,7 +677,9 @@ static void aql_teardown(ssd_env *env) {
     aql_drain(env);
     for (uint64_t h : A.fork_sig) ssd::aql::signal_destroy(h);
     if (A.join_counter) (void)hipFree(A.join_counter);
+    if (A.fork_counter) (void)hipFree(A.fork_counter);
     ssd::aql::host_kernarg_free(A.flag_kernarg);
+    ssd::aql::host_kernarg_free(A.fork_kernarg);
     for (auto &st : A.sets) if (st.dev) (void)hipFree(st.dev);
     // (of the state pair, world_buf[0] / agents_buf[0] are the handle's original allocations: freed with env->allocs; if the
     // current state sits in the other pair, ssd_destroy frees whichever pointers env->p does not hold)
@@ -680,31 +687,6 @@ static void aql_teardown(ssd_env *env) {
     if (A.world_buf[1]) (void)hipFree(A.world_buf[1]);
     if (A.agents_buf[1]) (void)hipFree(A.agents_buf[1]);
     env->aql.reset();
-}
-
-// Is a profiling / tracing tool attached to this process?  Such tools may run kernels ONE AT A TIME (rocprofv3 --pmc does): a
-// kernel that waits for another queue's kernel -- the stream-side wait of the join, the chains' barrier on the fork signal --
-// would then never end.  With a tool attached the rollout calls therefore use host-side waits ("sync mode": the call itself
-// waits for the stream before and for the chains after; no kernel waits for another).  SSD_AQL_SYNC=1 / 0 forces / forbids that.
-// What counts as attached: the variables the ROCm tools are started with, or their libraries already loaded in the process.
-static int tool_attached_now() {
-    static const char *const vars[] = {"ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROF_COUNTER_COLLECTION", "ROCPROFILER_METRICS_PATH",
-                                       "ROCPROF_ATT_LIBRARY_PATH"};
-    for (const char *n : vars) { const char *v = getenv(n); if (v && *v) return 1; }
-    if (const char *pl = getenv("LD_PRELOAD")) { if (std::strstr(pl, "rocprof") || std::strstr(pl, "roctracer") || std::strstr(pl, "omnitrace") || std::strstr(pl, "rocsys")) return 1; }
-    static const char *const libs[] = {"librocprofiler-sdk.so.1", "librocprofiler-sdk.so", "librocprofiler-sdk-tool.so", "librocprofiler64.so.2",
-                                       "librocprofiler64.so.1", "librocprofiler64.so"};
-    for (const char *l : libs)
-        if (void *h = dlopen(l, RTLD_LAZY | RTLD_NOLOAD)) { dlclose(h); return 1; }
-    return 0;
-}
-static bool aql_sync_mode() {
-    static const bool v = [] {
-        const char *e = getenv("SSD_AQL_SYNC");
-        if (e && *e) return atoi(e) != 0;
-        return tool_attached_now() != 0;
-    }();
-    return v;
 }
 
 // Queues for `chains` chains, fork signals: created once.  false: use hipLaunchKernel.
@@ -725,11 +707,17 @@ static bool aql_ready(ssd_env *env, int chains) {
         A.flag_kernarg = ssd::aql::host_kernarg_alloc(env->device, 64);
         if (!A.flag_kernarg) return false;
         std::memcpy(A.flag_kernarg, &A.join_counter, sizeof(void *));
+        ptr = nullptr;
+        if (hipMalloc(&ptr, 8) != hipSuccess || hipMemset(ptr, 0, 8) != hipSuccess) { (void)hipGetLastError(); return false; }
+        A.fork_counter = static_cast<unsigned long long *>(ptr);
+        A.fork_kernarg = static_cast<uint8_t *>(ssd::aql::host_kernarg_alloc(env->device, AqlState::kForks * AqlState::kForkBlock));
+        if (!A.fork_kernarg || !ssd::aql::lookup(env->device, ssd::wait_kernel_fn(), &A.wait_kernel) || A.wait_kernel.kernarg_size > AqlState::kForkBlock) return false;
         {   // first launches of the two helper kernels now (the runtime resolves a kernel on its first launch: ~50 us), not
             // inside somebody's first short rollout -- and before the pool's first queue is probed (the probe launches one of them)
             ssd::aql::signal_set(A.fork_sig[0], 1);
             ssd::launch_signal_kernel(ssd::aql::signal_value_ptr(A.fork_sig[0]), nullptr);
             ssd::launch_wait_counter_kernel(A.join_counter, 0, nullptr, 0, nullptr, nullptr);
+            ssd::launch_flag_kernel(A.fork_counter, nullptr); A.forks = 1;
             if (hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipGetLastError(); return false; }
         }
         A.q[0] = ssd::aql::pool_queue(env->device, 0);
@@ -912,7 +900,7 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     static const bool always_fork = SSD_HOOK("SSD_AQL_ALWAYS_FORK", 0) != 0;
     // Sync mode: the call itself waits -- for the stream before, for the chains after -- and no kernel waits for another queue's
     // kernel.  Chosen automatically when a profiling tool is attached (aql_sync_mode), or with SSD_AQL_SYNC=1.
-    const bool sync_mode = aql_sync_mode();
+    const bool sync_mode = ssd::aql::sync_mode();
     if (sync_mode) { SSD_HIP(env, hipStreamSynchronize(s)); env->last_path |= SSD_PATH_SYNC; }
     bool stream_idle = sync_mode || (!always_fork && hipStreamQuery(s) == hipSuccess);
     if (!stream_idle && !always_fork) {
@@ -928,13 +916,33 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
         const int slot = A.fork_next;
         A.fork_next = (A.fork_next + 1) % AqlState::kForks;
         for (int c = 0; c < A.nq; ++c) { aql_wait_consumed(A.q[c], A.fork_used[slot][c]); A.fork_used[slot][c] = 0; }
-        ssd::aql::signal_set(A.fork_sig[slot], 1);
-        ssd::launch_signal_kernel(ssd::aql::signal_value_ptr(A.fork_sig[slot]), s);
-        // (nothing is in the library's queues yet: an error here leaves nothing behind)
-        if (hipGetLastError() != hipSuccess) { env->err = "fork kernel launch failed"; return SSD_E_DEVICE; }
-        for (int c = 0; c < chains; ++c) {
-            ssd::aql::barrier_and(A.q[c], A.fork_sig[slot]);
-            A.fork_used[slot][c] = ssd::aql::write_index(A.q[c]);     // (= index of the barrier packet + 1)
+        // Two forms.  (1) A one-wave kernel on the stream bumps a counter in device memory, and every chain starts with a one-wave
+        // dispatch that polls it (the join's construct, the other way round).  (0) A kernel on the stream zeroes an HSA signal that a
+        // barrier-AND packet at the head of every chain waits on: the command processor then polls the signal, at its own pace
+        // (measured: a 20-step call from a stream with a 2 us kernel pending: 13.4 us per step against 6.5 from an idle stream).
+        static const int fork_kind = SSD_HOOK("SSD_AQL_FORK_KIND", 1);
+        if (fork_kind == 1) {
+            A.forks++;
+            ssd::launch_flag_kernel(A.fork_counter, s);
+            // (nothing is in the library's queues yet: an error here leaves nothing behind)
+            if (hipGetLastError() != hipSuccess) { A.forks--; env->err = "fork kernel launch failed"; return SSD_E_DEVICE; }
+            // (the wait is bounded -- a minute: what the stream holds ahead of the call may be a whole training step)
+            ssd::WaitArgs wa{A.fork_counter, A.forks, ssd::aql::abort_flag_dev(env->device), 6000000000ull, env->p.status};
+            uint8_t *ka = A.fork_kernarg + (size_t)slot * AqlState::kForkBlock;
+            std::memcpy(ka, &wa, sizeof wa);
+            for (int c = 0; c < chains; ++c) {
+                ssd::aql::dispatch(A.q[c], A.wait_kernel, 1, 64, 0, ka, /*barrier=*/true, 0, 0);
+                A.fork_used[slot][c] = ssd::aql::write_index(A.q[c]);
+            }
+        } else {
+            ssd::aql::signal_set(A.fork_sig[slot], 1);
+            ssd::launch_signal_kernel(ssd::aql::signal_value_ptr(A.fork_sig[slot]), s);
+            // (nothing is in the library's queues yet: an error here leaves nothing behind)
+            if (hipGetLastError() != hipSuccess) { env->err = "fork kernel launch failed"; return SSD_E_DEVICE; }
+            for (int c = 0; c < chains; ++c) {
+                ssd::aql::barrier_and(A.q[c], A.fork_sig[slot]);
+                A.fork_used[slot][c] = ssd::aql::write_index(A.q[c]);     // (= index of the barrier packet + 1)
+            }
         }
         env->last_path |= SSD_PATH_FORKED;
     }
@@ -1036,14 +1044,22 @@ static int rollout(ssd_env *env, const int32_t *actions, const uint8_t *order, i
     // GPU busy while the other chain's kernel drains and the next one is dispatched -- the ~2 us per launch that a single
     // chain of dependent kernels cannot hide.  SSD_ROLLOUT_CHAINS overrides.
     static const int forced = SSD_KNOB("SSD_ROLLOUT_CHAINS", 0);
-    int chains = env->rollout_chains > 0 ? env->rollout_chains : forced > 0 ? forced : (env->E < 2048 ? 1 : (env->E >= 6144 && env->E <= 24576) ? 3 : 2);   // measured: profiles/r01_sweep_envs.txt
+    auto by_size = [&]() { return env->E < 2048 ? 1 : (env->E >= 6144 && env->E <= 24576) ? 3 : 2; };   // measured: profiles/r01_sweep_envs.txt
+    int chains = env->rollout_chains > 0 ? env->rollout_chains : forced > 0 ? forced : by_size();
     if ((flags & SSD_ROLLOUT_FUSED) && env->rollout_chains <= 0 && forced <= 0) chains = 1;   // one launch already covers the whole rollout
-    // (an automatic choice stays within the library's own dispatch queues: ssd_aql.hip, pool_size())
-    if (env->rollout_chains <= 0 && forced <= 0 && chains > ssd::aql::pool_size(env->device)) chains = ssd::aql::pool_size(env->device);
-    if (chains > 8) chains = 8;
-    if (chains > env->E) chains = env->E;
-    if (chains < 1) chains = 1;
-    env->last_path = (chains << 8) | ((flags & SSD_ROLLOUT_FUSED) ? SSD_PATH_FUSED : 0);
+    const bool automatic = env->rollout_chains <= 0 && forced <= 0;
+    // (an automatic choice stays within the library's own dispatch queues -- ssd_aql.hip, pool_size() -- and where the probe found
+    // the process past the hardware-queue cliff already, every further active queue or stream would be time-sliced against the
+    // others: one chain on the caller's own stream)
+    auto clamp_chains = [&]() {
+        if (automatic && ssd::aql::pool_size(env->device) >= 1 && chains > ssd::aql::pool_size(env->device)) chains = ssd::aql::pool_size(env->device);
+        if (automatic && ssd::aql::over_the_cliff(env->device)) chains = 1;
+        if (chains > 8) chains = 8;
+        if (chains > env->E) chains = env->E;
+        if (chains < 1) chains = 1;
+        env->last_path = (chains << 8) | ((flags & SSD_ROLLOUT_FUSED) ? SSD_PATH_FUSED : 0);
+    };
+    clamp_chains();
     auto range = [&](int c) { return (int)(((long long)env->E * c) / chains); };
     auto job_of = [&](int c, hipStream_t cs) {
         ChainJob j;
@@ -1055,12 +1071,20 @@ static int rollout(ssd_env *env, const int32_t *actions, const uint8_t *order, i
     };
     if (!(flags & SSD_ROLLOUT_FUSED)) {
         // the library's own dispatch path: the same launches as below, written as AQL packets into its own queues
-        ChainJob jobs[8];
-        for (int c = 0; c < chains; ++c) jobs[c] = job_of(c, s);
-        const int rc = rollout_aql(env, chains, jobs, s);
-        env->last_path |= ssd::aql::pool_report(env->device);
-        if (rc <= 0) return rc;
-        env->last_path &= ~(SSD_PATH_AQL | SSD_PATH_COHERENT | SSD_PATH_SPLIT | SSD_PATH_SYNC | SSD_PATH_FORKED);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            ChainJob jobs[8];
+            for (int c = 0; c < chains; ++c) jobs[c] = job_of(c, s);
+            const int pool_before = ssd::aql::pool_size(env->device);
+            const int rc = rollout_aql(env, chains, jobs, s);
+            env->last_path |= ssd::aql::pool_report(env->device);
+            if (rc <= 0) return rc;
+            env->last_path &= ~(SSD_PATH_AQL | SSD_PATH_COHERENT | SSD_PATH_SPLIT | SSD_PATH_SYNC | SSD_PATH_FORKED);
+            // (this call created a queue that failed its probe: an automatic chain count is chosen again for the pool that is left)
+            if (!automatic || ssd::aql::pool_size(env->device) >= pool_before) break;
+            chains = by_size();
+            clamp_chains();
+            env->last_path |= ssd::aql::pool_report(env->device);
+        }
     }
     if (chains <= 1) {
         int rc = rollout_chain(env, job_of(0, s));
@@ -1130,7 +1154,7 @@ int ssd_rollout_actions(ssd_env *env, const int32_t *actions, const uint8_t *ord
     return rollout(env, actions, order, action_ring, 0, n_steps, reset_every, step0, obs, rew, done, ring, flags, stream);
 }
 
-int ssd_profiler_attached(void) { return tool_attached_now(); }
+int ssd_profiler_attached(void) { return ssd::aql::tool_attached_now(); }
 
 int ssd_observe(ssd_env *env, void *obs, uint32_t flags, void *stream) {
     if (!env || !obs) return SSD_E_INVALID;

@@ -132,6 +132,10 @@ bool select(const Params &p, int game, Launch *out);   // resolve a launch witho
 void launch(const Launch &L, void *stream);            // hipLaunchKernel of a resolved launch
 void launch(const Params &p, int game, void *stream);
 const void *flag_kernel_fn();                          // ssd_flag_kernel's host stub (AQL join)
+const void *wait_kernel_fn();                          // ssd_wait_counter_kernel's host stub (AQL fork: a chain's first packet)
+void launch_flag_kernel(unsigned long long *counter, void *stream);   // AQL fork: bump a counter from a HIP stream
+// the kernel arguments of ssd_wait_counter_kernel as its kernarg segment lays them out
+struct WaitArgs { const unsigned long long *counter; unsigned long long target; const uint32_t *abort; unsigned long long timeout_ticks; uint32_t *status; };
 // the stream-side wait of the AQL join: gives up after `timeout_ticks` of the 100 MHz clock and then sets kStWaitTimeout in *status
 void launch_wait_counter_kernel(const unsigned long long *counter, unsigned long long target, const uint32_t *abort,
                                 unsigned long long timeout_ticks, uint32_t *status, void *stream);

@@ -1704,6 +1704,10 @@ void launch_clock_kernel(unsigned long long *out, int iters, void *stream) {
 }
 #endif
 const void *flag_kernel_fn() { return reinterpret_cast<const void *>(&ssd_flag_kernel); }
+const void *wait_kernel_fn() { return reinterpret_cast<const void *>(&ssd_wait_counter_kernel); }
+void launch_flag_kernel(unsigned long long *counter, void *stream) {
+    hipLaunchKernelGGL(ssd_flag_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), counter);
+}
 void launch_wait_counter_kernel(const unsigned long long *counter, unsigned long long target, const uint32_t *abort,
                                 unsigned long long timeout_ticks, uint32_t *status, void *stream) {
     hipLaunchKernelGGL(ssd_wait_counter_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), counter, target, abort,
