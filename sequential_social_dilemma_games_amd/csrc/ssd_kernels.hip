@@ -371,9 +371,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 u32x4_t g0[kGridLoads];
                 const uint8_t *gsrc = a_world + (size_t)eb * S;
 #pragma unroll
+                // (every lane loads, lanes past the grid's end the last 16 bytes again: an asm load under a divergent branch would
+                // leave the compiler free to copy its -- not yet written -- destination register when the branches join)
                 for (int j = 0; j < kGridLoads; ++j) {
-                    g0[j] = u32x4_t{0u, 0u, 0u, 0u};
-                    if (lane * 16 + j * 1024 < S) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g0[j]) : "v"(gsrc + lane * 16 + j * 1024) : "memory");
+                    const int off = lane * 16 + j * 1024;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g0[j]) : "v"(gsrc + (off < S ? off : S - 16)) : "memory");
                 }
                 uint32_t areg = 0;
                 if (lane < N) areg = __hip_atomic_load(a_agents + (size_t)eb * N + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -395,8 +397,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 if (snapshot) {                                         // (rare: the overlay as the step left it, instead of the state)
                     gsrc = p.snap_in + (size_t)eb * S;
 #pragma unroll
-                    for (int j = 0; j < kGridLoads; ++j)
-                        if (lane * 16 + j * 1024 < S) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g0[j]) : "v"(gsrc + lane * 16 + j * 1024) : "memory");
+                    for (int j = 0; j < kGridLoads; ++j) {
+                        const int off = lane * 16 + j * 1024;
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g0[j]) : "v"(gsrc + (off < S ? off : S - 16)) : "memory");
+                    }
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0[0]) : : "memory");
 #pragma unroll
                     for (int j = 1; j < kGridLoads; ++j) asm volatile("" : "+v"(g0[j]));
@@ -467,9 +471,25 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // lanes out after the common wait shortens the wave by 0.2 us (diagnostic build: load phase 1605 -> 1138 cycles) and
         // makes the 4096-env step SLOWER, 5.35 -> 5.53 us (Cleanup 5.79 -> 5.95; no difference at 1024 or 16 384 envs):
         // with two chains of launches in flight the step is not the wave's latency alone, and the staggered loads suit it)
+        // kPre (Cleanup, the map-specific coherent step kernels).  Cleanup's spawn pass starts with a DEPENDENT fetch: the two
+        // thresholds of the current waste count (cleanup.py:156-171 through the host's tables), a scalar load that can only go
+        // out once the beams have said how many cells they cleaned -- a round trip to L2 in the middle of the wave, with nothing
+        // to overlap it.  Here a window of both tables is requested in the prologue instead, lane l taking the entries of
+        // (count in the header - l): the spawn pass then reads its pair out of lane `cells cleaned this step` (almost always
+        // < 64; else the fetch as before).
+        // Measured (Cleanup 48 x 36, 10 agents, 2048 envs, alternating fresh processes): 8.18 -> 7.90 us per step; 25 x 18 x 4096:
+        // 5.97 -> 5.90.  Tried on top of it and dropped: the respawn's keyed draws (up to 23 per lane on the 48 x 36 map) computed
+        // in the prologue too, in the shadow of the grid's loads -- lists and window requested ahead of the grid as inline-asm
+        // loads, s_waitcnt vmcnt(<grid pieces>) -- 8.30 us: the load phase grows by more than the spawn pass shrinks (every wave
+        // of the launch multiplies at the same moment); the lists requested before the header has arrived: 8.72.  (And a lesson
+        // kept: a load the compiler cannot see must not sit under a divergent branch, nor have much code between it and its
+        // wait -- the compiler is free to copy or reuse its destination register before the data lands.)
+        constexpr bool kPre = GAME == 1 && MODE == kModeStep && COH && FAST != 0;
         uint4 hdr;
         if (kCoh) {
             const uint32_t hv = cload(reinterpret_cast<const uint32_t *>(a_hdr + e) + (lane & 3));
+            // (these kernel arguments are fetched while the header is on its way)
+            if constexpr (kPre) asm volatile("" ::"s"(p.waste_cells), "s"(p.thr_ca), "s"(p.thr_cw), "s"(p.n_thr));
             hdr = make_uint4(rl(hv, 0), rl(hv, 1), rl(hv, 2), rl(hv, 3));
         } else {
             hdr = a_hdr[e];
@@ -485,18 +505,23 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         constexpr int kGridLoads = FAST ? (fm.S + 1023) / 1024 : 1;
         uint4 w0[kGridLoads], b0 = make_uint4(0, 0, 0, 0);
         u32x4_t w0c[kGridLoads];                                        // (coherent variants: the asm loads' destinations)
+        auto issue_grid = [&]() {
 #pragma unroll
-        for (int j = 0; j < kGridLoads; ++j) {
-            w0[j] = make_uint4(0, 0, 0, 0);
-            w0c[j] = u32x4_t{0u, 0u, 0u, 0u};
-            if (lane * 16 + j * 1024 < S) {
+            for (int j = 0; j < kGridLoads; ++j) {
+                w0[j] = make_uint4(0, 0, 0, 0);
+                w0c[j] = u32x4_t{0u, 0u, 0u, 0u};
+                const int off = lane * 16 + j * 1024;
                 if (kCoh) {
-                    w0c[j] = cload16(gsrc + lane * 16 + j * 1024);
-                } else {
-                    w0[j] = *reinterpret_cast<const uint4 *>(gsrc + lane * 16 + j * 1024);
+                    // (every lane loads, lanes past the grid's end the last 16 bytes again: an asm load under a divergent branch
+                    // would leave the compiler free to copy its -- not yet written -- destination when the branches join;
+                    // only lanes inside the grid store what they loaded)
+                    w0c[j] = cload16(gsrc + (off < S ? off : S - 16));
+                } else if (off < S) {
+                    w0[j] = *reinterpret_cast<const uint4 *>(gsrc + off);
                 }
             }
-        }
+        };
+        issue_grid();
         if (lane * 16 < S && mode == kModeObserve && keep_beams) b0 = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + lane * 16);
         // glyph -> RGB table of the observation phase, one copy per wave
         // (a launch that renders nothing -- the env waves of a split rollout, a reset inside one -- needs no colour table)
@@ -531,6 +556,15 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             const int idx = lane + 64 * j;
             wlist[j] = 0u;
             if (GAME == 1 && 64 * j < n_waste) wlist[j] = (mode != kModeObserve && idx < n_waste) ? p.waste_cells[idx] : 0u;
+        }
+        // kPre: thresholds by waste count, lane l holding those of (count in the header - l): the spawn pass will see the count
+        // less what this step's CLEAN beams clean (cleanup.py:115 after :94-111), almost always within the window
+        uint64_t thr_pa = 0, thr_pw = 0;
+        if constexpr (kPre) {
+            int ti = (int)(rfl(hdr.w) >> 16) - lane;
+            ti = ti < 0 ? 0 : ti;
+            ti = ti < p.n_thr ? ti : p.n_thr - 1;
+            thr_pa = p.thr_ca[ti]; thr_pw = p.thr_cw[ti];
         }
         if (kCoh) {                                                      // (the asm loads above)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0c[0]) : : "memory");
@@ -1205,7 +1239,17 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     uint32_t nh = waste_cur - cleaned;                                  // compute_permitted_area (:173-179), kept incrementally
                     waste_count = nh;
                     nh = nh < (uint32_t)p.n_thr ? nh : (uint32_t)p.n_thr - 1;
-                    const uint64_t thr_a = p.thr_ca[nh], thr_w = p.thr_cw[nh];
+                    uint64_t thr_a = 0, thr_w = 0;
+                    bool thr_have = false;                                              // (wave-uniform) the prologue's window serves
+                    if constexpr (kPre) {
+                        const uint32_t back = rfl(cleaned);                             // the window's lane: cells cleaned this step
+                        if (back < 64u) {
+                            thr_a = (uint64_t)rl((uint32_t)thr_pa, back) | ((uint64_t)rl((uint32_t)(thr_pa >> 32), back) << 32);
+                            thr_w = (uint64_t)rl((uint32_t)thr_pw, back) | ((uint64_t)rl((uint32_t)(thr_pw >> 32), back) << 32);
+                            thr_have = true;
+                        }
+                    }
+                    if (!thr_have) { thr_a = p.thr_ca[nh]; thr_w = p.thr_cw[nh]; }
                     auto apple = [&](int j, uint32_t c, bool valid) {                   // :135-141
                         c = valid ? c : safe;
                         const uint8_t w = s_world[c & 0xFFFFu], o = s_occ[c & 0xFFFFu];

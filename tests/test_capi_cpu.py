@@ -116,3 +116,21 @@ def test_profiler_detection(var, want):
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert int(r.stdout.decode().strip().splitlines()[-1]) == want
+
+
+def test_inflight_asm_loads_are_not_touched_before_their_wait():
+    """The coherent kernels fetch an env's grid with inline-asm agent-scope loads the compiler cannot see as outstanding.  Nothing
+    may read or write their destination registers before the s_waitcnt that covers them (tools/check_asm_loads.py on the ISA of the
+    committed sources; round 3 lost a grid piece to a load under a divergent branch, and a kernel to asm loads with much code
+    between issue and wait)."""
+    import shutil
+    import subprocess
+    import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(REPO, "sequential_social_dilemma_games_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "ARCH=gfx950", "asm"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_asm_loads.py"), os.path.join(csrc, "ssd_kernels.s")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]

