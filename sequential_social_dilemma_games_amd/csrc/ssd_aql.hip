@@ -442,7 +442,8 @@ static bool probe_pool_queue(DeviceCtx *c, Queue *Q, int index) {
     if (!probe_on) return true;
     // (a profiling tool is attached: it may run kernels one at a time -- the burst's waiting kernel would sit out its time bound --
     // and its timings say nothing about the unprofiled process: no probe, the rule's pool size stands)
-    if (sync_mode()) { say("probe skipped: a profiling tool is attached (host-side waits)"); return true; }
+    // (whatever SSD_AQL_SYNC says about the waits: a tracer's per-dispatch overhead alone makes the first queue look time-sliced)
+    if (sync_mode() || tool_attached_now()) { say("probe skipped: a profiling tool is attached"); return true; }
     Queue *qs[kPoolSlots];
     int nq = 0;
     for (int i = 0; i < index && i < kPoolSlots - 1; ++i) if (c->pool[i]) qs[nq++] = c->pool[i];

@@ -616,6 +616,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // the last spawn pass used, ssd_get_waste_count): a step only changes it by the cells its CLEAN beams clean and the
         // one waste cell it may spawn, so compute_permitted_area (cleanup.py:173-179) need not recount the grid.
         uint32_t waste_cur = GAME == 1 ? rfl(hdr.w) >> 16 : 0u;
+        // (measured and dropped, round 3: the grid written back right after the beams -- its stores then overlap the spawn pass --
+        // and only the 16-byte pieces the spawn pass changed written again at the end: Harvest 4096 envs 5.50 against 5.50 us per
+        // step (a first pair of runs said 5.43 against 5.54: box noise), 2048 envs 4.68 against 4.61, 8192 envs 10.56 against
+        // 10.37, Cleanup 25 x 18 5.96 against 5.87, 48 x 36 8.14 against 7.73: the stores are not what the wave's end waits for)
         auto write_state = [&](const uint32_t render_flags) {
             uint8_t *gw = a_world + (size_t)e * S;
             if constexpr (kCoh) {
@@ -1236,9 +1240,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 } else {
                     // cleanup.py:113-116: compute_probabilities (:156-171) from the current waste count, then
                     // spawn_apples_and_waste (:132-154).  Thresholds come from a host-computed table.
-                    uint32_t nh = waste_cur - cleaned;                                  // compute_permitted_area (:173-179), kept incrementally
+                    const uint32_t nh = waste_cur - cleaned;                            // compute_permitted_area (:173-179), kept incrementally
                     waste_count = nh;
-                    nh = nh < (uint32_t)p.n_thr ? nh : (uint32_t)p.n_thr - 1;
                     uint64_t thr_a = 0, thr_w = 0;
                     bool thr_have = false;                                              // (wave-uniform) the prologue's window serves
                     if constexpr (kPre) {
@@ -1249,7 +1252,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                             thr_have = true;
                         }
                     }
-                    if (!thr_have) { thr_a = p.thr_ca[nh]; thr_w = p.thr_cw[nh]; }
+                    if (!thr_have) {                                                    // (the table's size is fetched only here)
+                        const uint32_t ni = nh < (uint32_t)p.n_thr ? nh : (uint32_t)p.n_thr - 1;
+                        thr_a = p.thr_ca[ni]; thr_w = p.thr_cw[ni];
+                    }
                     auto apple = [&](int j, uint32_t c, bool valid) {                   // :135-141
                         c = valid ? c : safe;
                         const uint8_t w = s_world[c & 0xFFFFu], o = s_occ[c & 0xFFFFu];
