@@ -600,6 +600,20 @@ def main():
                                  "polls); median of %d runs" % (args.steps, len(walls)),
                         "us_per_step": bw * 1e6 / args.steps, "us_per_call": bw * 1e6, "forked": p["forked"]}
             run_leg(holder, "busy_stream_call", busy_call)
+        # ---- optional leg: the rollout into a RING of 32 output slots (what a trainer that keeps a trajectory does).  The headline's one
+        #      slot (13.8 MB, rewritten every step) lives in the device's 256-MB memory-side cache; 32 slots (442 MB) do not, and the
+        #      observation stores then stream to HBM (non-temporal write-through: the library's choice past 232 MB) ----
+        if plain and world == 1 and args.ring <= 1:
+            def ring_leg():
+                R = 32
+                big = tuple(torch.empty((R,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in out)
+                n = max(256, args.steps)
+                rw, _, _ = time_rollout(torch, eng, big, n, 64, step0=args.warmup + args.steps)
+                us = rw * 1e6 / n
+                return {"label": "NOT the headline: the same rollout into a ring of %d output slots (%d MB of observations: past the 256-MB "
+                                 "memory-side cache that absorbs the headline's single slot)" % (R, R * big[0][0].numel() * big[0].element_size() >> 20),
+                        "steps": n, "us_per_step": us, "roofline_frac": bytes_env * E / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            run_leg(holder, "output_ring_32", ring_leg)
         # ---- optional leg, reported separately and labelled: the same K steps as ONE fused kernel launch --
         #      every env resident in LDS / registers across its steps (SSD_ROLLOUT_FUSED).  Not part of `value`. ----
         if plain and not args.obs_f32:

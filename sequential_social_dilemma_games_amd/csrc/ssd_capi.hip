@@ -552,6 +552,11 @@ static ChainCursor chain_cursor(const ssd_env *env, const ChainJob &j) {
     c.s = j.s; c.obs = j.obs; c.rew = j.rew; c.done = j.done;
     c.actions = j.actions; c.order = j.order; c.action_ring = j.action_ring;
     c.en = (size_t)env->E * env->N; c.ob = obs_bytes(env, f32);
+    // An output ring whose observations do not fit the device's 256-MB memory-side cache: the write-through stores bypass it
+    // (non-temporal).  One slot rewritten every step lives in that cache (4096 envs: 13.8 MB, 5.43 us per step; 6.91 if it
+    // bypassed it); 16 slots (221 MB) still do: 5.50 (7.06 bypassing); 32 slots (442 MB) thrash it: 8.07 us per step, with
+    // non-temporal stores 7.03 (`python bench.py --ring R`, alternating fresh processes).
+    c.p.obs_nt = (j.obs && (size_t)j.ring * c.ob > ((size_t)232 << 20)) ? 1 : 0;
     c.num_actions = j.num_actions; c.reset_every = j.reset_every; c.step0 = j.step0; c.ring = j.ring;
     return c;
 }
@@ -592,6 +597,7 @@ static int rollout_chain(ssd_env *env, const ChainJob &j) {
         p.actions = j.actions; p.order = j.actions ? j.order : nullptr; p.action_ring = j.actions ? j.action_ring : 0;
         p.n_steps = n_steps; p.reset_every = j.reset_every; p.step0 = j.step0; p.ring = j.ring;
         p.obs = j.obs; p.rew = j.rew; p.done = j.done;
+        p.obs_nt = (j.obs && (size_t)j.ring * obs_bytes(env, false) > ((size_t)232 << 20)) ? 1 : 0;
         ssd::launch(p, env->game, s);
         return hipGetLastError() == hipSuccess ? SSD_OK : SSD_E_DEVICE;
     }

@@ -46,7 +46,8 @@ struct Params {
     int32_t A0, A1;                // LDS aprons of the world layer (bytes, multiples of 16): view_len rows of '0' above / below
     int32_t view_len, V, beam_len;
     int32_t mode, rotate, keep_beams, num_actions_random;
-    int32_t obs_wt;                // observation stores are write-through (sc1); set per launch by launch()
+    int32_t obs_wt;                // observation stores: 0 ordinary, 1 write-through (sc1), 2 write-through + non-temporal; set per launch by select()
+    int32_t obs_nt;                // the call's observation ring does not fit the memory-side cache: ask for 2 where 1 would be chosen
     int32_t obs_f32;               // obs is float32 [E,N,V,V,3] (SSD_OBS_F32) instead of uint8
     int32_t n_steps, reset_every, step0, ring, E_total;   // kModeRollout: steps in this launch, reset period (0 = never), index of the
                                    // first step, slots in the output ring, env count of the handle (slot stride)

@@ -130,13 +130,18 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // `wt` (wave-uniform, Params::obs_wt) picks the policy per launch: once a launch is many rounds of waves (above 16 384
 // envs per launch, two launches in flight) the kernel is bandwidth-bound, L2 merging of the 12-byte pieces matters more than the final flush, and ordinary
 // stores win (65 536 envs: 53.6 vs 69.4 us).
-__device__ __forceinline__ void store12_wt(uint8_t *base, uint32_t off, u32x3_t d, bool wt) {
-    // (`sc1 nt`, non-temporal on top: 6.91 against 5.34 us per 4096-env step -- the stores then seem to bypass the memory-side cache)
-    if (wt) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+// wt = 2: `sc1 nt`, non-temporal on top: the stores bypass the 256-MB memory-side cache.  With ONE output slot (13.8 MB at 4096
+// envs, rewritten every step) that cache absorbs the observation stores altogether -- 5.43 us per step, and 6.91 with `nt` -- but an
+// output ring that does not fit in it (32 slots: 442 MB) thrashes it: 8.07 us per step with plain write-through stores.  So the host
+// asks for `nt` when the ring's observation bytes exceed what the cache can hold (ssd_capi.hip: obs_nt).
+__device__ __forceinline__ void store12_wt(uint8_t *base, uint32_t off, u32x3_t d, int wt) {
+    if (wt == 2) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1 nt\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+    else if (wt) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
     else asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
 }
-__device__ __forceinline__ void store16_wt(float *base, uint32_t off, f32x4_t d, bool wt) {
-    if (wt) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+__device__ __forceinline__ void store16_wt(float *base, uint32_t off, f32x4_t d, int wt) {
+    if (wt == 2) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1 nt\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+    else if (wt) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
     else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
 }
 
@@ -153,7 +158,7 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
 // cell 0 of the layer the views show.  (agent.py:76-78 -> utility_funcs.py:59-114, map_env.py:316-339, :669-689.)
 template <int NA>
 __device__ __forceinline__ void render_views_std(const int lane, const int WP, const uint32_t a_k, const uint32_t a_s0, const uint32_t view_lds,
-                                                 const uint32_t *s_lut, uint8_t *out_env, const bool wt) {
+                                                 const uint32_t *s_lut, uint8_t *out_env, const int wt) {
     typedef __attribute__((address_space(3))) const uint8_t lds_u8;
     constexpr int V = 15, VV = 225, kB = 5;
     const int pp_raw = 4 * lane;
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 SSD_BSTAMP(1, __builtin_readcyclecounter());                // layer ready
                 const uint32_t kq = orientb == 2 ? 0u : orientb == 0 ? 1u : orientb == 3 ? 2u : 3u;     // rotate_view: UP 0, LEFT 1, DOWN 2, RIGHT 3
                 const uint32_t s0 = (uint32_t)((int)cellb - 7 * (WP + 1) + (kq >= 2 ? 14 * (WP + 1) : 0));
-                render_views_std<NA>(lane, WP, kq, s0, (uint32_t)(uintptr_t)(lds_u8 *)s_world, s_lut, p.obs_b + (size_t)eb * N * 675, true);
+                render_views_std<NA>(lane, WP, kq, s0, (uint32_t)(uintptr_t)(lds_u8 *)s_world, s_lut, p.obs_b + (size_t)eb * N * 675, p.obs_wt);
                 SSD_BSTAMP(2, __builtin_readcyclecounter());                // stores issued
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 SSD_BSTAMP(3, __builtin_readcyclecounter());                // stores landed
@@ -1456,12 +1461,12 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                             o.y = r0 ? t[0].y : r1 ? t[0].z : t[1].x;
                             o.z = r0 ? t[0].z : r1 ? t[1].x : t[1].y;
                             o.w = r0 ? t[1].x : r1 ? t[1].y : t[1].z;
-                            if (on) store16_wt(base_env + (size_t)ag * nf, (uint32_t)f0 * 4u, o, p.obs_wt != 0);
+                            if (on) store16_wt(base_env + (size_t)ag * nf, (uint32_t)f0 * 4u, o, p.obs_wt);
                         }
                     }
                 } else if constexpr (STD && NA > 0 && NA % 5 == 0 && !F32) {
                     // Specialised kernels: five agents per pass (render_views_std)
-                    render_views_std<NA>(lane, WP, a_k, a_s0, world_lds, s_lut, out_env, p.obs_wt != 0);
+                    render_views_std<NA>(lane, WP, a_k, a_s0, world_lds, s_lut, out_env, p.obs_wt);
                 } else
                 for (int base = 0; base < VV; base += 256) {
                     // A lane renders 4 consecutive cells = one 12-byte store.  V*V is not a multiple of 4 (225 = 56*4 + 1):
@@ -1519,7 +1524,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
 #pragma unroll
                                     for (int k4 = 0; k4 < 3; ++k4) {
                                         f32x4_t v4 = {f[4 * k4], f[4 * k4 + 1], f[4 * k4 + 2], f[4 * k4 + 3]};
-                                        store16_wt(basef, (uint32_t)pp0 * 12u + 16u * k4, v4, p.obs_wt != 0);
+                                        store16_wt(basef, (uint32_t)pp0 * 12u + 16u * k4, v4, p.obs_wt);
                                     }
                                 }
                             } else {
@@ -1540,7 +1545,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                                 d.x = __builtin_amdgcn_perm(px[1], px[0], 0x04020100u);   // r0 g0 b0 r1
                                 d.y = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);   // g1 b1 r2 g2
                                 d.z = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);   // b2 r3 g3 b3
-                                store12_wt(out_env + (size_t)ag * VV * 3, off3, d, p.obs_wt != 0);
+                                store12_wt(out_env + (size_t)ag * VV * 3, off3, d, p.obs_wt);
                             }
                         } else {
 #pragma unroll
@@ -1667,6 +1672,7 @@ bool select(const Params &p_in, int game, Launch *out) {
     // per launch (rollouts run two launches at a time); float32 observations are 4x the bytes: a quarter of the envs
     p.obs_wt = forced_wt >= 0 ? forced_wt : ((p.E - p.e_begin) <= (p.obs_f32 ? 4096 : 16384) ? 1 : 0);
     if (p.coherent) p.obs_wt = 1;                   // (a coherent launch leaves nothing dirty in L2)
+    if (p.obs_nt && p.obs_wt == 1) p.obs_wt = 2;    // (an output ring beyond the memory-side cache: write-through AND non-temporal)
     static const int forced_epb = SSD_KNOB("SSD_ENVS_PER_BLOCK", 0);
     const bool f32 = p.obs && p.obs_f32;            // the float32-observation variant is a separate instantiation
     int epb = envs_per_block(p, f32);
