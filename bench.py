@@ -585,20 +585,31 @@ def main():
         #      loop: policy kernels are still queued), so that the call forks from it -- the headline's region starts on an idle stream
         if plain:
             def busy_call():
-                x = torch.zeros(1 << 20, device="cuda")
-                walls = []
-                for rep_i in range(5):             # (median of 5: one shot of a ~140 us region is noisy)
+                x = torch.zeros(1 << 24, device="cuda")       # 64 MB: the pending kernel lasts ~30 us, the call must fork from the stream
+                x.add_(1.0)
+                torch.cuda.synchronize()
+                alone = []
+                for _ in range(7):
+                    t1 = time.perf_counter()
+                    x.add_(1.0)
+                    torch.cuda.synchronize()
+                    alone.append(time.perf_counter() - t1)
+                alone_us = sorted(alone)[len(alone) // 2] * 1e6
+                walls, forked = [], False
+                for rep_i in range(5):             # (median of 5: one shot of a ~170 us region is noisy)
                     bw, _, _ = time_rollout(torch, eng, ring, args.steps, 4 if rep_i == 0 else 0, step0=args.warmup + args.steps + 8 + rep_i * args.steps,
                                             busy=lambda: x.add_(1.0))
                     walls.append(bw)
+                    forked = forked or eng.rollout_path()["forked"]
                     if args.steps > 200:
                         break
-                p = eng.rollout_path()
                 bw = sorted(walls)[len(walls) // 2]
-                return {"label": "NOT the headline: the same %d steps with a (4 MB, ~2 us) kernel pending on the stream when the call comes; "
-                                 "the call then forks from the stream (a one-wave kernel on the stream bumps a counter the chains' first packet "
-                                 "polls); median of %d runs" % (args.steps, len(walls)),
-                        "us_per_step": bw * 1e6 / args.steps, "us_per_call": bw * 1e6, "forked": p["forked"]}
+                return {"label": "NOT the headline: the same %d steps called while a 64-MB elementwise kernel is still pending on the stream, so "
+                                 "that the call forks from the stream (a one-wave kernel on the stream bumps a counter the chains' first packet "
+                                 "polls); median of %d runs; the pending kernel's own duration is subtracted in us_per_step_beyond_pending"
+                                 % (args.steps, len(walls)),
+                        "us_per_call": bw * 1e6, "pending_kernel_alone_us": alone_us,
+                        "us_per_step_beyond_pending": (bw * 1e6 - alone_us) / args.steps, "forked": forked}
             run_leg(holder, "busy_stream_call", busy_call)
         # ---- optional leg: the rollout into a RING of 32 output slots (what a trainer that keeps a trajectory does).  The headline's one
         #      slot (13.8 MB, rewritten every step) lives in the device's 256-MB memory-side cache; 32 slots (442 MB) do not, and the

@@ -300,7 +300,7 @@ constexpr FastMap kFastMap[2][3] = {
 // write-back / invalidate between them -- the library's own dispatch queues (ssd_aql.hip) then order them with the packet's
 // barrier bit alone (release fence NONE: -0.85 us per step).  (Round 2 also had a variant whose waves waited env by env on pass
 // counters, "pipelined launches": 4.44 against 4.50 us per step at 2048 envs, nothing at 4096 -- removed in round 3.)
-template <int GAME, int MODE, bool F32, int NA, bool STD, int FAST, bool COH = false>
+template <int GAME, int MODE, bool F32, int NA, bool STD, int FAST, bool COH = false, bool ACTS = false>
 // The leading arguments repeat the Params fields the first global loads need (14 dwords).  Built with
 // -mllvm -amdgpu-kernarg-preload-count=14 the command processor delivers them in SGPRs when the wave starts, so the
 // loads of the env's state go out without first waiting ~0.3 us for a scalar load of the kernel arguments.
@@ -669,7 +669,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // A fused rollout with caller-supplied actions (ssd_rollout_actions): step k reads slot (step0 + k) % action_ring of
         // p.actions [action_ring][E_total][N].  The load for the NEXT step pass goes out at the start of the current pass, so its
         // round trip to memory is off the env's path.
-        const bool roll_acts = roll && p.action_ring > 0;
+        // (ACTS: a specialisation of its own -- the slot counter and the prefetched actions / orders are loop-carried registers, and
+        // the rollout kernels are short of them: carried by the random-action kernel as well they cost it 8 %, 3.7 -> 4.0 us per step)
+        constexpr bool roll_acts = roll && ACTS;
         uint32_t aslot = 0;
         int act_next = -1;
         uint32_t ord_next = 0xFFu;
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             }
             aslot = aslot + 1 == (uint32_t)p.action_ring ? 0u : aslot + 1;
         };
-        if (roll_acts) { aslot = (uint32_t)(p.step0 % p.action_ring); fetch_action(); }
+        if constexpr (roll_acts) { aslot = (uint32_t)(p.step0 % p.action_ring); fetch_action(); }
         for (;;) {
             const bool is_reset = (roll || auto_mode) ? in_reset : (mode == kModeReset);
             const bool is_step = (roll || auto_mode) ? !in_reset : (mode == kModeStep);
@@ -737,7 +739,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 t += 1;
                 // ---- actions (map_env.py:171-173) ----
                 constexpr int kNumActions = GAME == 0 ? 8 : 9;   // harvest.py:44, cleanup.py:70
-                if (roll_acts) {                                 // (fused rollout, caller-supplied actions: fetched a pass ago)
+                if constexpr (roll_acts) {                       // (fused rollout, caller-supplied actions: fetched a pass ago)
                     act = act_next; ord_in = ord_next;
                     fetch_action();                              // (the slot after the call's last step is read and ignored)
                     const bool bad = is_agent && (act < -1 || act >= kNumActions);
@@ -1408,6 +1410,12 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 const int V = STD ? 15 : p.V, v = STD ? 7 : p.view_len, VV = V * V;
                 // (diagnostic builds, skip bit 4: all envs write the first 64 envs' blocks -- same instructions, no HBM write stream)
                 uint8_t *out_env = a_obs + (slot_en + (size_t)(SSD_SKIP(4) ? (e & 63) : e) * N) * VV * 3;
+                if constexpr (roll) {
+                    // (wave-uniform by construction, but in the rollout kernels' loop the compiler does not always see it -- and the
+                    // store helpers take their base address in scalar registers)
+                    const uint64_t ob = reinterpret_cast<uint64_t>(out_env);
+                    out_env = reinterpret_cast<uint8_t *>(((uint64_t)rfl((uint32_t)(ob >> 32)) << 32) | (uint64_t)rfl((uint32_t)ob));
+                }
                 // Per-agent constants, computed once with lane = agent and read back as scalars in the loop.
                 // Window cell (a, b) of an agent on grid cell `cell` is grid cell cell + (a - v) * WP + (b - v).
                 // The view is rot90^k of the window (rotate_view, map_env.py:669-689; UP 0, LEFT 1, DOWN 2,
@@ -1603,15 +1611,18 @@ __global__ void ssd_render_full_kernel(const Params p, int e0, uint8_t *rgb) {
 
 // Host-side handle (the __global__ stub) of one instantiation: what hipLaunchKernel takes, and what names the kernel's
 // descriptor in the code object for the library's own AQL dispatches (ssd_aql.hip).
-template <int GAME, int MODE, bool F32, int NA, bool STD, int FAST, bool COH = false>
+template <int GAME, int MODE, bool F32, int NA, bool STD, int FAST, bool COH = false, bool ACTS = false>
 static const void *kernel_fn() {
-    return reinterpret_cast<const void *>(&ssd_env_kernel<GAME, MODE, F32, NA, STD, FAST, COH>);
+    return reinterpret_cast<const void *>(&ssd_env_kernel<GAME, MODE, F32, NA, STD, FAST, COH, ACTS>);
 }
 
 template <int GAME, bool F32, int NA, bool STD, int FAST>
 static const void *select_step(const Params &p) {
     if (p.mode == kModeRollout) {
-        if constexpr (!F32) return kernel_fn<GAME, kModeRollout, false, NA, STD, FAST>();
+        if constexpr (!F32) {
+            if (p.action_ring > 0) return kernel_fn<GAME, kModeRollout, false, NA, STD, FAST, false, true>();
+            return kernel_fn<GAME, kModeRollout, false, NA, STD, FAST>();
+        }
         return nullptr;
     } else if (p.mode == kModeStepAuto) {
         if constexpr (!F32) return kernel_fn<GAME, kModeStepAuto, false, NA, STD, FAST>();

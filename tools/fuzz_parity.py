@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity fuzz (GPU box; not part of the suite): random wall-closed maps, agent counts, views, beam lengths and
-env counts, stepped four ways -- call by call with random action subsets / orders, ssd_rollout_random as chains, as the
-fused rollout kernel, and with SSD_AUTO_RESET -- against the C oracle, bit for bit.
+env counts, stepped five ways -- call by call with random action subsets / orders, ssd_rollout_random as chains, as the
+fused rollout kernel, ssd_rollout_actions (caller-supplied action and order rings; chains and fused), and with SSD_AUTO_RESET --
+against the C oracle, bit for bit.  First line: the library that ran and the SSD_* settings (tools/_label.py).
 
     python tools/fuzz_parity.py [n_configs] [seed]"""
 import os
@@ -119,6 +120,39 @@ def run(c, quiet=False):
                 tag + " rollout fused=%d step %d" % (fused, k)
         check_state(eng, ora, tag + " after rollout fused=%d" % fused)
         step0 += n
+    # (3b) ssd_rollout_actions: caller-supplied actions, and every other call the action dicts' orders (a generator of its own, keyed
+    #      by the configuration's seed: what `draw` consumes stays what it always was)
+    rng2 = np.random.RandomState((seed ^ 0x5A5A5A) & 0x7FFFFFFF)
+    na = 8 if game == K.GAME_HARVEST else 9
+    for call, fused in enumerate((False, True, False, True)):
+        n2, aring = int(rng2.randint(1, 8)), int(rng2.randint(1, 6))
+        n2 = min(n2, aring)                                   # (a slot is read once per call)
+        eng.set_rollout_chains(int(rng2.randint(1, 4)))
+        a_host = rng2.randint(0, na, size=(aring, E, N)).astype(np.int32)
+        o_host = None
+        if call >= 2:
+            o_host = np.full((aring, E, N), 0xFF, np.uint8)
+            for r_ in range(aring):
+                for e in range(E):
+                    k = rng2.randint(0, N + 1)
+                    perm = rng2.permutation(N)[:k]
+                    o_host[r_, e, :k] = perm
+                    a_host[r_, e, np.setdiff1d(np.arange(N), perm)] = -1
+        else:
+            a_host[rng2.rand(aring, E, N) < 0.2] = -1
+        a_dev = torch.from_numpy(a_host).cuda()
+        o_dev = torch.from_numpy(o_host).cuda() if o_host is not None else None
+        want = {}
+        for k in range(step0, step0 + n2):
+            o_obs, o_rew, _ = ora.step(a_host[k % aring], None if o_host is None else o_host[k % aring])
+            want[k] = (o_obs, o_rew)
+        eng.rollout_actions(a_dev, n2, obs, rew, done, reset_every=0, step0=step0, fused=fused, order=o_dev)
+        g_obs, g_rew = obs.cpu().numpy(), rew.cpu().numpy()
+        for k in range(max(step0, step0 + n2 - ring), step0 + n2):
+            assert np.array_equal(g_obs[k % ring], want[k][0]) and np.array_equal(g_rew[k % ring], want[k][1]), \
+                tag + " rollout_actions call %d fused=%d step %d" % (call, fused, k)
+        check_state(eng, ora, tag + " after rollout_actions call %d" % call)
+        step0 += n2
     # (4) auto-reset in the step launch, envs out of phase
     Hz = c["horizon"]
     eng.set_horizon(Hz)
@@ -152,6 +186,9 @@ def replay_cfg215(variants=12):
 
 
 def main():
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from _label import label
+    label("fuzz_parity " + " ".join(sys.argv[1:]))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     for i in range(n):
