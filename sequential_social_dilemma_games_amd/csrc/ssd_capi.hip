@@ -217,7 +217,11 @@ int fail_create(const std::string &msg, int code) {
     return code;
 }
 
+#ifdef SSD_EXP_OBS768   // (experiment builds only: see ssd_kernels.hip)
+size_t obs_bytes(const ssd_env *env, bool f32 = false) { return f32 ? (size_t)env->E * env->N * env->V * env->V * 3 * 4 : (size_t)env->E * env->N * SSD_EXP_OBS768; }
+#else
 size_t obs_bytes(const ssd_env *env, bool f32 = false) { return (size_t)env->E * env->N * env->V * env->V * 3 * (f32 ? 4 : 1); }
+#endif
 
 int ensure_staging(ssd_env *env) {
     if (env->st_obs) return SSD_OK;
