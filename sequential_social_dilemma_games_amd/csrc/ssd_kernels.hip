@@ -140,6 +140,14 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // envs, rewritten every step) that cache absorbs the observation stores altogether -- 5.43 us per step, and 6.91 with `nt` -- but an
 // output ring that does not fit in it (32 slots: 442 MB) thrashes it: 8.07 us per step with plain write-through stores.  So the host
 // asks for `nt` when the ring's observation bytes exceed what the cache can hold (ssd_capi.hip: obs_nt).
+// What then bounds the stores is that the two ends of every agent block (675 bytes: any alignment) are 64-byte sectors written
+// partly by one store instruction and partly by another: with the blocks padded to 704 / 768 bytes (NOT the output layout) a ring
+// of 32 slots takes 5.95 / 5.74 us per step against 6.96; dword alignment alone (676) 6.81.  Getting that inside the real layout
+// was built and measured (commit ae4b8b6: the env's N x 675 bytes written as ONE stream of 16-byte pieces aligned in memory, eight
+// whole lines per instruction, the block's two partial ends as 8 / 4 / 2 / 1-byte pieces; bit-exact): the memory system is relieved
+// as hoped -- env waves 15 % shorter, stores land in 950 cycles instead of 2 700 -- but a piece's 16 bytes are 5 1/3 view cells of
+// up to two agents, so cell coordinates become per-lane arithmetic where the 12-byte form has per-lane CONSTANTS: the renderer's
+// render phase grows from 3 100 to 5 400 cycles and the renderer wave becomes the launch's critical path: 7.6 against 7.03 us.
 __device__ __forceinline__ void store12_wt(uint8_t *base, uint32_t off, u32x3_t d, int wt) {
     if (wt >= 2) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1 nt\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
     else if (wt) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
@@ -156,103 +164,6 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
     uint32_t m = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
     return (m >> 7) * 0xFFu;
 }
-// The same observations written as ONE byte stream per env in 16-byte pieces aligned in memory (the env's N x 675 bytes are
-// contiguous: agent blocks follow each other).  Lane l of round r takes the piece at (block start rounded down to 128) + 16 x
-// (64 r + l): every store instruction then covers eight whole 128-byte lines, and only the block's first and last line are
-// shared with the neighbouring envs' waves -- with the 12-byte-per-lane stores above, every agent block's two ends are 64-byte
-// sectors written partly by one instruction and partly by another.  That does not matter while the output lives in the memory-
-// side cache, and it is what bounds the stores once it does not: measured with agent blocks padded to 704 / 768 bytes (not the
-// output layout) into a ring of 32 slots: 5.95 / 5.74 against 6.96 us per step; dword alignment alone (676): 6.81.  The price is
-// arithmetic -- a piece's 16 bytes are 5 1/3 cells, possibly of two agents, so agent and view coordinates are per-lane values --,
-// which is why this form is only used where the stores are the bound (wt == 2: the host's choice for output rings beyond the
-// cache).  `s_tab` is the wave's 64 dwords of LDS scratch: per agent (at most 32) the LDS address the window arithmetic starts
-// from, and the two multipliers that turn view row / column into an LDS offset for its rotation.
-template <int NA>
-__device__ __forceinline__ void render_stream_aligned(const int lane, const int WP, const uint32_t a_k, const uint32_t a_s0, const uint32_t view_lds,
-                                                      const uint32_t *s_lut, uint32_t *s_tab, uint8_t *out_env) {
-    typedef __attribute__((address_space(3))) const uint8_t lds_u8;
-    constexpr int B = NA * 675, kRounds = (127 + B + 1023) / 1024;
-    static_assert(NA <= 32, "two table entries per agent in 64 dwords of scratch");
-    if (lane < NA) {
-        // window cell (i, j) of the view sits at LDS byte  base + i * mi + j * mj  (rotate_view, map_env.py:669-689; `a_s0` already
-        // points at the window's first cell for k < 2 and at its last for k >= 2):
-        //   k = 0: s0 + i WP + j      k = 1: s0 + j WP + (14 - i)      k = 2: s0 - (i WP + j)      k = 3: s0 - (j WP + 14 - i)
-        const int k = (int)a_k;
-        const int mi = k == 0 ? WP : k == 1 ? -1 : k == 2 ? -WP : 1;
-        const int mj = k == 0 ? 1 : k == 1 ? WP : k == 2 ? -1 : -WP;
-        const int c0 = k == 1 ? 14 : k == 3 ? -14 : 0;
-        s_tab[lane] = (uint32_t)((int)(a_s0 + view_lds) + c0);
-        s_tab[32 + lane] = ((uint32_t)mi & 0xFFFFu) | ((uint32_t)mj << 16);
-    }
-    wave_sync();
-    const uint64_t G = reinterpret_cast<uint64_t>(out_env);
-    const int head = (int)((uint32_t)G & 127u);                            // (wave-uniform)
-    uint8_t *const base128 = out_env - head;
-    for (int r = 0; r < kRounds; ++r) {
-        const int c = r * 64 + lane;
-        const int o_raw = 16 * c - head;                                   // stream byte of the piece's first byte
-        const bool any = (o_raw + 16 > 0) & (o_raw < B), full = (o_raw >= 0) & (o_raw + 16 <= B);
-        // The block's first and last piece (two lanes of the wave at most) hold fewer than 16 of this env's bytes -- the rest of
-        // their 16 bytes are the neighbouring envs'.  Such a lane renders the 16 stream bytes that START with its valid ones
-        // (n of them, at stream byte sp) and writes them as pieces of 8 / 4 / 2 / 1 bytes.
-        const int sp = !any ? 0 : o_raw < 0 ? 0 : o_raw;                   // (idle lanes: any valid position)
-        const int n = full ? 16 : any ? ((o_raw + 16 < B ? o_raw + 16 : B) - sp) : 0;
-        const int p0 = (int)(((uint32_t)sp * 43691u) >> 17);               // sp / 3 (sp < 2^15)
-        const int ch0 = sp - 3 * p0;
-        const int ag = (int)(((uint32_t)p0 * 37283u) >> 23);               // p0 / 225 (p0 < 2^14)
-        const int v0 = p0 - 225 * ag;
-        const int i0 = (int)(((uint32_t)v0 * 4370u) >> 16);                // v0 / 15 (v0 < 225)
-        const int j0 = v0 - 15 * i0;
-        const int ag1 = ag + 1 < NA ? ag + 1 : NA - 1;                     // (cells past the block's end -- the last piece only -- repeat the last agent's: never stored)
-        const uint32_t b_a = s_tab[ag], m_a = s_tab[32 + ag], b_b = s_tab[ag1], m_b = s_tab[32 + ag1];
-        const int mi_a = (int)(short)(m_a & 0xFFFFu), mj_a = (int)m_a >> 16, mi_b = (int)(short)(m_b & 0xFFFFu), mj_b = (int)m_b >> 16;
-        uint32_t px[6];
-        uint32_t addr[6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            int j = j0 + q, i = i0;
-            if (j >= 15) { j -= 15; i += 1; }
-            const bool next = i >= 15;                                     // past the agent's 225 cells: the next agent's first row
-            if (next) i -= 15;
-            addr[q] = (uint32_t)((int)(next ? b_b : b_a) + __mul24(i, next ? mi_b : mi_a) + __mul24(j, next ? mj_b : mj_a));
-        }
-        uint32_t gl[6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) gl[q] = *(lds_u8 *)(uintptr_t)addr[q];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) px[q] = s_lut[gl[q]];
-        // 6 x (r, g, b) = 18 bytes of stream; the piece is its bytes ch0 .. ch0 + 15
-        const uint32_t S0 = px[0] | (px[1] << 24), S1 = (px[1] >> 8) | (px[2] << 16), S2 = (px[2] >> 16) | (px[3] << 8),
-                       S3 = px[4] | (px[5] << 24), S4 = px[5] >> 8;
-        u32x4_t d;
-        d.x = __builtin_amdgcn_alignbyte(S1, S0, (uint32_t)ch0);
-        d.y = __builtin_amdgcn_alignbyte(S2, S1, (uint32_t)ch0);
-        d.z = __builtin_amdgcn_alignbyte(S3, S2, (uint32_t)ch0);
-        d.w = __builtin_amdgcn_alignbyte(S4, S3, (uint32_t)ch0);
-        if (full) {
-            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1 nt\n\ts_nop 1" ::"v"((uint32_t)(16 * c)), "v"(d), "s"(base128) : "memory");
-        }
-        if (ballot(any & !full)) {
-            const bool part = any & !full;
-            uint8_t *dst = out_env + sp;
-            int off = 0;                                                   // bytes of d written so far
-            if (part & ((n & 8) != 0)) {
-                __hip_atomic_store(reinterpret_cast<uint32_t *>(dst), d.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(reinterpret_cast<uint32_t *>(dst + 4), d.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            off = n & 8;
-            const uint32_t w4 = off ? d.z : d.x;
-            if (part & ((n & 4) != 0)) __hip_atomic_store(reinterpret_cast<uint32_t *>(dst + off), w4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            off += n & 4;
-            const uint32_t w2 = off >= 12 ? d.w : off >= 8 ? d.z : off >= 4 ? d.y : d.x;
-            if (part & ((n & 2) != 0)) __hip_atomic_store(reinterpret_cast<uint16_t *>(dst + off), (uint16_t)(w2 >> (8 * (off & 3))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            off += n & 2;
-            const uint32_t w1 = off >= 12 ? d.w : off >= 8 ? d.z : off >= 4 ? d.y : d.x;
-            if (part & ((n & 1) != 0)) __hip_atomic_store(dst + off, (uint8_t)(w1 >> (8 * (off & 3))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
 // The observation phase of the reference configuration (view_len 7: V = 15) for NA agents, five per pass: lane = 4 consecutive
 // cells of the 15 x 15 view = one 12-byte store (the lane holding the leftover 225th cell starts 4 cells before the end and
 // re-renders 3 cells of its neighbour, so that every store is a full 12 bytes).  All grid reads of a pass go out together, then
@@ -261,15 +172,9 @@ __device__ __forceinline__ void render_stream_aligned(const int lane, const int 
 // cell 0 of the layer the views show.  (agent.py:76-78 -> utility_funcs.py:59-114, map_env.py:316-339, :669-689.)
 template <int NA>
 __device__ __forceinline__ void render_views_std(const int lane, const int WP, const uint32_t a_k, const uint32_t a_s0, const uint32_t view_lds,
-                                                 const uint32_t *s_lut, uint32_t *s_tab, uint8_t *out_env, const int wt) {
+                                                 const uint32_t *s_lut, uint8_t *out_env, const int wt) {
     typedef __attribute__((address_space(3))) const uint8_t lds_u8;
     constexpr int V = 15, VV = 225, kB = 5;
-#ifndef SSD_EXP_OBS768
-    if (wt == 3) {                                                       // (wave-uniform) an output ring beyond the memory-side cache
-        render_stream_aligned<NA>(lane, WP, a_k, a_s0, view_lds, s_lut, s_tab, out_env);
-        return;
-    }
-#endif
     const int pp_raw = 4 * lane;
     const bool lane_on = pp_raw < VV;
     const int pp0 = pp_raw > VV - 4 ? VV - 4 : pp_raw;                  // lanes past the end repeat the last one
@@ -547,7 +452,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 SSD_BSTAMP(1, __builtin_readcyclecounter());                // layer ready
                 const uint32_t kq = orientb == 2 ? 0u : orientb == 0 ? 1u : orientb == 3 ? 2u : 3u;     // rotate_view: UP 0, LEFT 1, DOWN 2, RIGHT 3
                 const uint32_t s0 = (uint32_t)((int)cellb - 7 * (WP + 1) + (kq >= 2 ? 14 * (WP + 1) : 0));
-                render_views_std<NA>(lane, WP, kq, s0, (uint32_t)(uintptr_t)(lds_u8 *)s_world, s_lut, s_lut + 128, p.obs_b + (size_t)eb * N * SSD_OBS_STRIDE, p.obs_wt);
+                render_views_std<NA>(lane, WP, kq, s0, (uint32_t)(uintptr_t)(lds_u8 *)s_world, s_lut, p.obs_b + (size_t)eb * N * SSD_OBS_STRIDE, p.obs_wt);
                 SSD_BSTAMP(2, __builtin_readcyclecounter());                // stores issued
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 SSD_BSTAMP(3, __builtin_readcyclecounter());                // stores landed
@@ -1587,7 +1492,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     }
                 } else if constexpr (STD && NA > 0 && NA % 5 == 0 && !F32) {
                     // Specialised kernels: five agents per pass (render_views_std)
-                    render_views_std<NA>(lane, WP, a_k, a_s0, world_lds, s_lut, s_tmp, out_env, p.obs_wt);
+                    render_views_std<NA>(lane, WP, a_k, a_s0, world_lds, s_lut, out_env, p.obs_wt);
                 } else
                 for (int base = 0; base < VV; base += 256) {
                     // A lane renders 4 consecutive cells = one 12-byte store.  V*V is not a multiple of 4 (225 = 56*4 + 1):
@@ -1796,10 +1701,9 @@ bool select(const Params &p_in, int game, Launch *out) {
     // per launch (rollouts run two launches at a time); float32 observations are 4x the bytes: a quarter of the envs
     p.obs_wt = forced_wt >= 0 ? forced_wt : ((p.E - p.e_begin) <= (p.obs_f32 ? 4096 : 16384) ? 1 : 0);
     if (p.coherent) p.obs_wt = 1;                   // (a coherent launch leaves nothing dirty in L2)
-    static const int forced_nt = SSD_HOOK("SSD_OBS_NT", -1), stream = SSD_HOOK("SSD_OBS_STREAM", 0);   // (test-hook build: A / B)
+    static const int forced_nt = SSD_HOOK("SSD_OBS_NT", -1);   // (test-hook build: the non-temporal form whatever the ring's size)
     if (forced_nt >= 0) p.obs_nt = forced_nt;
-    // (an output ring beyond the memory-side cache: write-through AND non-temporal; 3: ... as one aligned byte stream per env)
-    if (p.obs_nt && p.obs_wt == 1) p.obs_wt = stream ? 3 : 2;
+    if (p.obs_nt && p.obs_wt == 1) p.obs_wt = 2;    // (an output ring beyond the memory-side cache: write-through AND non-temporal)
     static const int forced_epb = SSD_KNOB("SSD_ENVS_PER_BLOCK", 0);
     const bool f32 = p.obs && p.obs_f32;            // the float32-observation variant is a separate instantiation
     int epb = envs_per_block(p, f32);
