@@ -146,7 +146,7 @@ def test_bench_line_survives_failing_legs():
     assert res["value"] > 1e8 and res["n_gpus"] == 1 and res["roofline"]["frac"] > 0 and res["config"]["dispatch_fallback_ranks"] == []
     for leg in ("fused_rollout", "policy_step", "configs", "cpu_baseline"):
         assert "injected failure" in res[leg]["error"], (leg, res[leg])
-    assert "call_overhead_us" in res and "us_per_step" in res["busy_stream_call"]       # the legs that were not told to fail ran
+    assert "call_overhead_us" in res and "us_per_call" in res["busy_stream_call"]       # the legs that were not told to fail ran
 
 
 _LOAD_SCRIPT = r'''

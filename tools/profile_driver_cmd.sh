@@ -1,11 +1,11 @@
 #!/bin/bash
 # tools/profile_driver_cmd.sh -- run ON THE GPU BOX: rocprofv3 --kernel-trace --stats of the driver's exact bench command
-# (python3 bench.py --gpus 1 --steps 20 --warmup 5); the summary lands in gpurun_out/r02_prof/driver_command/kernel_stats.csv.
+# (python3 bench.py --gpus 1 --steps 20 --warmup 5); the summary lands in gpurun_out/${ROUND:-r03}_prof/driver_command/kernel_stats.csv.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r02_prof/driver_command
+OUT=gpurun_out/${ROUND:-r03}_prof/driver_command
 mkdir -p "$OUT"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/trace.log" 2>&1
+SSD_AQL_SYNC=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/trace.log" 2>&1
 echo "rc=$?"
 cp $(find "$OUT/trace" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv"
 grep '^{' "$OUT/trace.log" | tail -1 > "$OUT/bench_under_trace.json"
