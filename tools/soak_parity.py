@@ -46,7 +46,7 @@ def main():
     t0 = time.time()
     checks = 0
     rsum = 0
-    R = int(os.environ.get("SOAK_RING", "1"))                  # output ring slots (pipelined launches need >= 2)
+    R = int(os.environ.get("SOAK_RING", "1"))                  # output ring slots
     import torch
     ring = tuple(t.unsqueeze(0) for t in out) if R == 1 else tuple(torch.zeros((R,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in out)
     if how != "step":
