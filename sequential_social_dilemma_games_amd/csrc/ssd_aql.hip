@@ -435,8 +435,8 @@ static double hip_burst_us(int n) {
 // queue that has a pipe to itself and 138 - 145 us on one that is time-sliced (gpurun_out/r03c/queue_probe3.txt) -- i.e. the
 // process is past the cliff before the library came (a host application with four busy streams): then the library holds no queue
 // at all and steps on the caller's own stream.
-// Medians of 3 bursts of 16.  Returns false when the new queue must go.
-static constexpr int kBurst = 16, kBurstReps = 3;
+// Medians of 5 bursts of 16.  Returns false when the new queue must go.
+static constexpr int kBurst = 16, kBurstReps = 5;
 static bool probe_pool_queue(DeviceCtx *c, Queue *Q, int index) {
     static const bool probe_on = SSD_HOOK("SSD_AQL_PROBE", 1) != 0;
     if (!probe_on) return true;
