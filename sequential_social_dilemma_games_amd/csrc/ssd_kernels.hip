@@ -499,7 +499,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // out once the beams have said how many cells they cleaned -- a round trip to L2 in the middle of the wave, with nothing
         // to overlap it.  Here a window of both tables is requested in the prologue instead, lane l taking the entries of
         // (count in the header - l): the spawn pass then reads its pair out of lane `cells cleaned this step` (almost always
-        // < 64; else the fetch as before).
+        // < 64; else the fetch as before).  (The compiler sinks the window's loads into the spawn pass -- they are vector loads
+        // there instead of two scalar loads behind a wait -- and pinning them into the prologue changes nothing: 7.68 against 7.70.)
         // Measured (Cleanup 48 x 36, 10 agents, 2048 envs, alternating fresh processes): 8.18 -> 7.90 us per step; 25 x 18 x 4096:
         // 5.97 -> 5.90.  Tried on top of it and dropped: the respawn's keyed draws (up to 23 per lane on the 48 x 36 map) computed
         // in the prologue too, in the shadow of the grid's loads -- lists and window requested ahead of the grid as inline-asm
