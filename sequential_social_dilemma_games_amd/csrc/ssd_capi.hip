@@ -105,7 +105,7 @@ struct AqlState {
     static_assert(sizeof(Set::geo[0]) / sizeof(Geo) == kKinds, "Set::geo holds one entry per kind");
     uint8_t *world_buf[2] = {};                     // split rollouts: the pair of state buffers ([0]: the handle's original ones)
     uint32_t *agents_buf[2] = {};
-    uint32_t *beam_list[2] = {};                    // [E][64] beam marks left by a launch of orientation o
+    uint32_t *beam_list[2] = {};                    // [2][E][64] beam marks left by a launch of orientation o (second half: a second pass's)
     uint8_t *snap_grid[2] = {};                     // [E][S] overlay snapshot left by a launch of orientation o (rare steps)
     static constexpr int kSets = 4;
     static constexpr size_t kBlock = 512;           // >= sizeof(ssd::KernArgs), a multiple of 64
@@ -757,7 +757,7 @@ static bool aql_split_buffers(ssd_env *env) {
     AqlState &A = *env->aql;
     if (A.world_buf[1] && A.agents_buf[1] && A.snap_grid[0] && A.snap_grid[1] && A.beam_list[0] && A.beam_list[1]) return true;
     const size_t sizes[6] = {(size_t)env->E * env->S, (size_t)env->E * (env->N ? env->N : 1) * 4, (size_t)env->E * env->S, (size_t)env->E * env->S,
-                             (size_t)env->E * 64 * 4, (size_t)env->E * 64 * 4};
+                             (size_t)env->E * 128 * 4, (size_t)env->E * 128 * 4};     // (beam lists: [E][64] + a second [E][64] for steps whose beams took two passes)
     void *buf[6] = {};
     for (int i = 0; i < 6; ++i)
         if (hipMalloc(&buf[i], sizes[i]) != hipSuccess) {

@@ -96,7 +96,8 @@ struct Params {
     int32_t snap_mode, blocks_a;
     uint8_t *world_out;            // [E][S]  null: state is written in place
     uint32_t *agents_out;          // [E][N]
-    uint32_t *beam_list;           // [E][64] cell | mark << 16 per lane of the step's beam trace; 0 none; 0xFFFFFFFF: see `snap`
+    uint32_t *beam_list;           // [2][E][64] cell | mark << 16 per lane of the step's beam trace; 0 none ([1]: the second pass of a Cleanup step with
+                                   // more shooters than one pass has slots, agent 0's bit 22)
     const uint32_t *beam_list_in;  // the previous step's
     uint8_t *snap;                 // [E][S]  overlay of the step (world <- agents <- beams), only after steps that could not list their marks
     const uint8_t *snap_in;        // the previous step's

@@ -30,6 +30,9 @@
 
 #include "ssd_internal.hpp"
 
+#ifndef SSD_WB_UNROLL          // (experiment switch: 0 = the write-back of a known map's grid as a loop)
+#define SSD_WB_UNROLL 1
+#endif
 #ifdef SSD_EXP_OBS768
 #define SSD_OBS_STRIDE SSD_EXP_OBS768
 #else
@@ -417,6 +420,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b;
                 const uint32_t flags = rfl(areg) >> 20;
                 const bool snapshot = (flags & 2u) != 0, marks = (flags & 1u) != 0;
+                // (bit 22: the step's beams took two passes -- the later pass's marks are in the second list)
+                uint32_t entry2 = 0;
+                constexpr bool kTwoLists = GAME == 1 && NA > 5;        // (as kTwoPasses of the env role below)
+                if (kTwoLists && (flags & 4u)) entry2 = __hip_atomic_load(p.beam_list_in + ((size_t)p.E_total + eb) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (snapshot) {                                         // (rare: the overlay as the step left it, instead of the state)
                     gsrc = p.snap_in + (size_t)eb * S;
 #pragma unroll
@@ -447,6 +454,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     if (marks) {
                         if (entry) s_world[entry & 0xFFFFu] = (uint8_t)(entry >> 16);
                         wave_sync();
+                        if constexpr (kTwoLists) {
+                            if (entry2) s_world[entry2 & 0xFFFFu] = (uint8_t)(entry2 >> 16);
+                            wave_sync();
+                        }
                     }
                 }
                 SSD_BSTAMP(1, __builtin_readcyclecounter());                // layer ready
@@ -653,6 +664,23 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 // (render_flags, split rollouts: what the renderer will find beside this state -- bits 20 / 21 of agent 0's
                 // word: a list of beam marks / an overlay snapshot; readers of the word take bits 0..17)
                 auto cstore = [](uint32_t *ptr, uint32_t v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+                if constexpr (FAST != 0 && SSD_WB_UNROLL) {
+                    // a known map's grid is kGridLoads pieces of 1 KiB: all of them are read out of LDS first, into registers of their
+                    // own, and the stores then follow each other -- as a loop (LDS read, wait, store, next piece into the same
+                    // registers) every piece waited for the one before
+                    uint4 v4[kGridLoads];
+#pragma unroll
+                    for (int j = 0; j < kGridLoads; ++j) {
+                        const int off = lane * 16 + j * 1024;
+                        v4[j] = *reinterpret_cast<const uint4 *>(s_world + (off < S ? off : 0));
+                    }
+#pragma unroll
+                    for (int j = 0; j < kGridLoads; ++j) {
+                        const int off = lane * 16 + j * 1024;
+                        const u32x4_t v = {v4[j].x, v4[j].y, v4[j].z, v4[j].w};
+                        if (off < S) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(gw + off), "v"(v) : "memory");
+                    }
+                } else
                 for (int i = lane * 16; i < S; i += 64 * 16) {
                     const uint4 v4 = *reinterpret_cast<const uint4 *>(s_world + i);
                     const u32x4_t v = {v4.x, v4.y, v4.z, v4.w};
@@ -955,6 +983,17 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             bool beams_in_regs = true, b_cov = false;
             int b_idx = 0;
             uint32_t b_chr = 0;
+            // Cleanup, more shooters than one pass has slots (10 agents: 4.5 % of random-action steps have five or more): the passes
+            // follow each other against the map as the earlier ones left it, and the FIRST pass's cells and marks are kept in a
+            // second set of registers -- the overlay patch and the split rollouts' beam list then take two entries per lane, the
+            // later pass's over the earlier's (firing order, map_env.py:299-300), instead of the step falling back to the merged
+            // overlay and its snapshot (+ 3 700 cycles on a wave that the launch then waits for).  Three passes: as before.
+            // Measured (48 x 36, 10 agents, 2048 envs, alternating fresh processes): 7.71 -> 7.28 us per step.  Kernels compiled for five
+            // agents leave it out (all five shooting: 0.05 % of steps; carrying the second set cost them 1.6 %, 6.05 -> 6.15).
+            constexpr bool kTwoPasses = GAME == 1 && !roll && (NA == 0 || NA > 5);
+            bool b_cov0 = false;
+            int b_idx0 = 0;
+            uint32_t b_chr0 = 0;
             if (!is_reset && !SSD_SKIP(1)) {
                 // ---- consume (map_env.py:178-181, agent.py:177-183) + occupancy layer ----
                 // Index order means: of several agents on one cell the LOWEST index eats the apple, and
@@ -1000,13 +1039,16 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     // a way that matters (below) let the slots land one after the other instead.  More shooters than slots
                     // (index action order): group after group, each against the map as the groups before left it.
                     const uint64_t all_shooters = shooters;
-                    beams_in_regs = __builtin_popcountll(all_shooters) <= G;            // one pass covers them all
+                    beams_in_regs = __builtin_popcountll(all_shooters) <= (kTwoPasses ? 2 * G : G);   // one pass covers them all (or two do)
+                    int pass_no = 0;
                     const int g = STD ? lane / 15 : lane / R, r = lane - g * R;
                     const int q = (r >= L) + (r >= 2 * L), kk = r - q * L;
                     const int cq = q == 1 ? 1 : q == 2 ? -1 : 0, ck = kk + (q == 0);   // ray cell = pos + cq * right + ck * d (:608-609)
                     const int sh = g * R + q * L;                                       // first lane of this lane's ray
                     const uint32_t packed_agent = cell | (orient << 16) | ((GAME == 1 && act == kClean) ? 1u << 20 : 0u);
                     while (shooters) {
+                        if (kTwoPasses && pass_no == 1) { b_cov0 = b_cov; b_idx0 = b_idx; b_chr0 = b_chr; }   // (the first pass's cells and marks)
+                        ++pass_no;
                         int a = -1, taken = 0;                                          // slot g <- the g-th remaining shooter
                         for (; taken < G && shooters; ++taken) {
                             const int b = __builtin_ctzll(shooters);
@@ -1341,8 +1383,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 if (!roll) {
                     uint32_t render_flags = 0;
                     if constexpr (stepping && COH) {
-                        if ((p.snap_mode & 1) && is_step)
-                            render_flags = (!keep_beams && beams_in_regs) ? (ballot(b_cov) ? 1u << 20 : 0u) : 1u << 21;
+                        if ((p.snap_mode & 1) && is_step) {
+                            render_flags = (!keep_beams && beams_in_regs) ? (ballot(b_cov | (kTwoPasses & b_cov0)) ? 1u << 20 : 0u) : 1u << 21;
+                            if constexpr (kTwoPasses)
+                                if (!keep_beams && beams_in_regs && ballot(b_cov0)) render_flags |= 1u << 22;   // (a second list: the later pass's marks)
+                        }
                     }
                     write_state(render_flags);
                 }
@@ -1380,9 +1425,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     // (which of the two the step left is said by two spare bits of agent 0's state word, written with the state
                     // above; the list is only written when there is a mark at all.  One dword per lane: staging it through LDS
                     // for 16-byte stores cost more on this wave's path than it saved, 5.29 against 5.15 us per step)
-                    if (patch && ballot(b_cov))
-                        __hip_atomic_store(p.beam_list + (size_t)e * 64 + lane, b_cov ? ((uint32_t)b_idx | (b_chr << 16)) : 0u,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // (two passes: the earlier pass's entries in the list proper, the later one's in a second list behind all envs' first)
+                    const bool two = kTwoPasses && ballot(b_cov0) != 0;
+                    const uint32_t ent = b_cov ? ((uint32_t)b_idx | (b_chr << 16)) : 0u, ent0 = b_cov0 ? ((uint32_t)b_idx0 | (b_chr0 << 16)) : 0u;
+                    if (patch && ballot(b_cov | b_cov0))
+                        __hip_atomic_store(p.beam_list + (size_t)e * 64 + lane, two ? ent0 : ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (patch && two)
+                        __hip_atomic_store(p.beam_list + ((size_t)p.E_total + e) * 64 + lane, ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             if (leave_overlay) {
@@ -1391,6 +1440,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     for (int i = lane * 16; i < S; i += 64 * 16)
                         *reinterpret_cast<uint4 *>(s_view + i) = *reinterpret_cast<const uint4 *>(s_world + i);
                 if (__builtin_amdgcn_inverse_ballot_w64(highest)) s_view[cell] = agent_glyph((uint32_t)lane);   // :289-297
+                if (kTwoPasses && b_cov0) s_view[b_idx0] = (uint8_t)b_chr0;                                     // (an earlier pass's marks first)
                 if (b_cov) s_view[b_idx] = (uint8_t)b_chr;                                                      // :299-300, over the agents
             } else if ((!roll || is_step) && !SSD_SKIP(5))   // (diagnostic builds: skip bit 5 = no overlay, to price it)
             for (int i = lane * 4; i < S; i += 64 * 4) {
