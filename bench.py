@@ -613,7 +613,7 @@ def main():
             run_leg(holder, "busy_stream_call", busy_call)
         # ---- optional leg: the rollout into a RING of 32 output slots (what a trainer that keeps a trajectory does).  The headline's one
         #      slot (13.8 MB, rewritten every step) lives in the device's 256-MB memory-side cache; 32 slots (442 MB) do not, and the
-        #      observation stores then stream to HBM (non-temporal write-through: the library's choice past 232 MB) ----
+        #      observation stores then stream to HBM (non-temporal write-back: the library's choice past 232 MB) ----
         if plain and world == 1 and args.ring <= 1:
             def ring_leg():
                 R = 32

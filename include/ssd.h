@@ -139,7 +139,8 @@ int ssd_step_random(ssd_env *env, int32_t num_actions, int32_t *actions_out, voi
  * with SSD_AQL=0 in the environment, through hipLaunchKernel on HIP streams.  Every step's outputs are in their ring slots
  * when the work enqueued by the call has completed on `stream`.
  * (An observation ring of more than 232 MB -- beyond what the device's 256-MB memory-side cache can hold next to the state -- is
- * written with non-temporal write-through stores: a ring that thrashes that cache costs 8.1 us per 4096-env step, past it 7.0;
+ * written with non-temporal write-back stores, flushed by the call's closing release and by an agent-scope release on one launch
+ * per round of the ring: a ring that thrashes that cache costs 8.1 us per 4096-env step, past it 5.8 (write-through: 7.0);
  * a single slot rewritten every step lives in it: 5.4.) */
 int ssd_rollout_random(ssd_env *env, int32_t num_actions, int32_t n_steps, int32_t reset_every, int32_t step0,
                        void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream);

@@ -966,6 +966,7 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     // (-0.14 us per step); the renderer workgroups of a split rollout read state and beam lists with agent-scope loads as well.
     const int kAcq = env_acq >= 0 ? env_acq : (coherent ? 0 : 1), kRel = env_rel >= 0 ? env_rel : (coherent ? 0 : 1);
     const int32_t reset_every = j0.reset_every, step0 = j0.step0, slots = key.slots;
+    const bool obs_wb = j0.obs && !key.f32 && (size_t)j0.ring * obs_bytes(env, false) > ((size_t)232 << 20);   // (chain_cursor's obs_nt)
     constexpr int kKinds = AqlState::kKinds;
     auto put = [&](int c, size_t i, int kind, bool barrier, int acq, int rel) {
         const AqlState::Geo &g = st->geo[c][kind];
@@ -988,7 +989,11 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
                 put(c, i, o * KO + (split ? AqlState::kRn : AqlState::kR), true, acq, kRel);
             }
             const int base = !split ? AqlState::kS : (pending && !reset) ? AqlState::kAB : AqlState::kA;
-            put(c, i, o * KO + base, true, reset ? kAcq : acq, kRel);
+            // (an output ring past the memory-side cache is written with write-back stores, ssd_kernels.hip select(): one launch per
+            // round of the ring releases at agent scope, so that whatever of a slot still sits dirty in an L2 is in memory before
+            // the slot's bytes are written again -- possibly through another XCD's L2)
+            const int rel = (obs_wb && (step0 + k) % j0.ring == 0) ? 1 : kRel;
+            put(c, i, o * KO + base, true, reset ? kAcq : acq, rel);
             if (split && k == j0.n_steps - 1) put(c, i, (1 - o) * KO + AqlState::kB, true, kAcq, kRel);   // (renders the buffer this step wrote)
             // (tried: the call's last step rendering itself, its renderer waves in the env's own workgroup behind a barrier -- with
             // a one-slot ring both write the same bytes -- instead of the renderer-only launch: 6.60 against 6.62 us per step of

@@ -143,16 +143,19 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // envs, rewritten every step) that cache absorbs the observation stores altogether -- 5.43 us per step, and 6.91 with `nt` -- but an
 // output ring that does not fit in it (32 slots: 442 MB) thrashes it: 8.07 us per step with plain write-through stores.  So the host
 // asks for `nt` when the ring's observation bytes exceed what the cache can hold (ssd_capi.hip: obs_nt).
-// What then bounds the stores is that the two ends of every agent block (675 bytes: any alignment) are 64-byte sectors written
-// partly by one store instruction and partly by another: with the blocks padded to 704 / 768 bytes (NOT the output layout) a ring
-// of 32 slots takes 5.95 / 5.74 us per step against 6.96; dword alignment alone (676) 6.81.  Getting that inside the real layout
+// What then bounds WRITE-THROUGH stores is that the two ends of every agent block (675 bytes: any alignment) are 64-byte sectors
+// written partly by one store instruction and partly by another: with the blocks padded to 704 / 768 bytes (NOT the output layout)
+// a ring of 32 slots takes 5.95 / 5.74 us per step against 6.96; dword alignment alone (676) 6.81.
+// wt = 3: `nt` alone -- write-BACK and non-temporal: the partial sectors meet in L2 and leave it as whole lines: 5.79 us per step in
+// the real layout; what uint8 observations use for such a ring (select() below).  Before that was found, merging inside the wave
 // was built and measured (commit ae4b8b6: the env's N x 675 bytes written as ONE stream of 16-byte pieces aligned in memory, eight
 // whole lines per instruction, the block's two partial ends as 8 / 4 / 2 / 1-byte pieces; bit-exact): the memory system is relieved
 // as hoped -- env waves 15 % shorter, stores land in 950 cycles instead of 2 700 -- but a piece's 16 bytes are 5 1/3 view cells of
 // up to two agents, so cell coordinates become per-lane arithmetic where the 12-byte form has per-lane CONSTANTS: the renderer's
 // render phase grows from 3 100 to 5 400 cycles and the renderer wave becomes the launch's critical path: 7.6 against 7.03 us.
 __device__ __forceinline__ void store12_wt(uint8_t *base, uint32_t off, u32x3_t d, int wt) {
-    if (wt >= 2) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1 nt\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+    if (wt == 3) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 nt\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+    else if (wt >= 2) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1 nt\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
     else if (wt) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
     else asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
 }
@@ -1754,7 +1757,17 @@ bool select(const Params &p_in, int game, Launch *out) {
     if (p.coherent) p.obs_wt = 1;                   // (a coherent launch leaves nothing dirty in L2)
     static const int forced_nt = SSD_HOOK("SSD_OBS_NT", -1);   // (test-hook build: the non-temporal form whatever the ring's size)
     if (forced_nt >= 0) p.obs_nt = forced_nt;
-    if (p.obs_nt && p.obs_wt == 1) p.obs_wt = 2;    // (an output ring beyond the memory-side cache: write-through AND non-temporal)
+    // An output ring beyond the memory-side cache.  uint8 observations: non-temporal write-BACK stores (3) -- the 12-byte pieces and
+    // the partly covered sectors at the ends of the agents' 675-byte blocks merge in L2 and leave it as whole lines, past the
+    // memory-side cache (ring 32: 5.79 us per step; write-through + non-temporal 6.86; ordinary write-back 7.04).  What a launch
+    // leaves dirty in the L2s is written back by the call's closing system-scope release -- and, so that no byte of a slot can still
+    // sit dirty in one XCD's L2 when another XCD writes it again a ring later, by an agent-scope release on one launch per round
+    // of the ring (ssd_capi.hip; HIP-launched plain kernels release after every launch anyway).  float32 observations are whole
+    // aligned lines per instruction already: write-through + non-temporal (2) as before.
+    if (p.obs_nt) p.obs_wt = p.obs_f32 ? (p.obs_wt == 1 ? 2 : p.obs_wt) : 3;
+#ifdef SSD_EXP_OBS_WB                               // (experiment: such a ring with another store policy)
+    if (p.obs_nt) p.obs_wt = SSD_EXP_OBS_WB;
+#endif
     static const int forced_epb = SSD_KNOB("SSD_ENVS_PER_BLOCK", 0);
     const bool f32 = p.obs && p.obs_f32;            // the float32-observation variant is a separate instantiation
     int epb = envs_per_block(p, f32);

@@ -57,12 +57,18 @@ def main():
     rng = np.random.RandomState(99)
     a_dev = torch.zeros((Kc, E, n_agents), dtype=torch.int32, device="cuda") if use_actions else None
     expect = os.environ.get("SOAK_EXPECT_PATH")
+    # SOAK_CHECK_ALL=1 (with SOAK_RING >= K): EVERY step's observations and rewards are compared, each in its ring slot, after the
+    # call that wrote them -- what a ring beyond the memory-side cache needs (its stores take another path: write-back,
+    # non-temporal, an agent-scope release once per round of the ring)
+    check_all = os.environ.get("SOAK_CHECK_ALL", "0") == "1"
+    assert not check_all or (how != "step" and R >= Kc)
+    chunk_want = {}
     for s in range(T):
         if s and s % 1000 == 0:
             ora.reset()
             if how == "step":
                 eng.reset(obs=out[0])
-        want_obs = (s % Kc == Kc - 1)
+        want_obs = (s % Kc == Kc - 1) or check_all
         if how == "step":
             obs, rew, _ = eng.step_random(out=out)
         elif s % Kc == 0:                                      # the Kc steps up to the next checkpoint in one library call
@@ -80,7 +86,15 @@ def main():
             o_obs, o_rew, _ = ora.step(a_host[s % Kc])
         else:
             _, o_obs, o_rew, _ = ora.step_random(want_obs=want_obs)
-        if want_obs:
+        if check_all:
+            chunk_want[s] = (o_obs, o_rew)
+            if s % Kc == Kc - 1:
+                g_obs, g_rew = ring[0].cpu().numpy(), ring[1].cpu().numpy()
+                for k, (w_obs, w_rew) in chunk_want.items():
+                    assert np.array_equal(g_rew[k % R], w_rew), "rewards of step %d (slot %d) differ after the call ending at step %d" % (k, k % R, s)
+                    assert np.array_equal(g_obs[k % R], w_obs), "observations of step %d (slot %d) differ after the call ending at step %d" % (k, k % R, s)
+                chunk_want.clear()
+        if want_obs and s % Kc == Kc - 1:
             r = rew.cpu().numpy()
             assert np.array_equal(r, o_rew), "rewards differ at step %d" % s
             assert np.array_equal(obs.cpu().numpy(), o_obs), "observations differ at step %d" % s
