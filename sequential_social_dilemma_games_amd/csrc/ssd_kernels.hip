@@ -492,7 +492,12 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         //      the first 1 KiB of the grid = the whole grid of the shipped maps, the colour table, the apple list), then
         //      the ones that need further kernel arguments (actions, order, waste list).
         // (COH: the env's state may have been written a moment ago by a wave on another XCD, i.e. behind another L2: agent-
-        // scope loads and stores, dword by dword, instead of cache write-backs / invalidations around ordinary ones)
+        // scope loads and stores, dword by dword, instead of cache write-backs / invalidations around ordinary ones.
+        // Measured once more in round 3: ORDINARY loads of header, agents and grid -- through this XCD's L2, every packet
+        // invalidating the CUs' L1s -- give bit-exact results over 1000 steps of 4096 envs (in practice an env's workgroup lands on
+        // the same XCD launch after launch) and are no faster, 5.57 against 5.43 us per step: the write-through stores of the launch
+        // before do not leave the lines in L2 to be hit, and the invalidate costs its 0.14 us.  Nothing to gain by speculating on it.
+        // And the grid's loads as `sc1 nt`: 6.10 against 5.48 -- the state is served by the memory-side cache, which `nt` goes past.)
         auto cload = [](const uint32_t *ptr) -> uint32_t {
             return kCoh ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ptr;
         };
@@ -1767,6 +1772,9 @@ bool select(const Params &p_in, int game, Launch *out) {
     if (p.obs_nt) p.obs_wt = p.obs_f32 ? (p.obs_wt == 1 ? 2 : p.obs_wt) : 3;
 #ifdef SSD_EXP_OBS_WB                               // (experiment: such a ring with another store policy)
     if (p.obs_nt) p.obs_wt = SSD_EXP_OBS_WB;
+#endif
+#ifdef SSD_EXP_OBS_WT_ALL                           // (experiment, unsafe: EVERY coherent launch's observation stores with this policy)
+    if (p.coherent) p.obs_wt = SSD_EXP_OBS_WT_ALL;
 #endif
     static const int forced_epb = SSD_KNOB("SSD_ENVS_PER_BLOCK", 0);
     const bool f32 = p.obs && p.obs_f32;            // the float32-observation variant is a separate instantiation
