@@ -30,6 +30,9 @@
 
 #include "ssd_internal.hpp"
 
+#ifndef SSD_PIN_EARLY          // (experiment switch: 0 = the prologue's kernel arguments requested where they always were)
+#define SSD_PIN_EARLY 1
+#endif
 #ifndef SSD_WB_UNROLL          // (experiment switch: 0 = the write-back of a known map's grid as a loop)
 #define SSD_WB_UNROLL 1
 #endif
@@ -533,6 +536,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             const uint32_t hv = cload(reinterpret_cast<const uint32_t *>(a_hdr + e) + (lane & 3));
             // (these kernel arguments are fetched while the header is on its way)
             if constexpr (kPre) asm volatile("" ::"s"(p.waste_cells), "s"(p.thr_ca), "s"(p.thr_cw), "s"(p.n_thr));
+#if SSD_PIN_EARLY
+            // ... and so are the ones the rest of the prologue and the respawn need (the pins further down): requested only after
+            // the header had arrived they were two scalar-cache round trips in a row, each holding up the vector loads behind it
+            asm volatile("" ::"s"(p.actions), "s"(p.order), "s"(p.num_actions_random), "s"(p.obs));
+            if (GAME == 1) asm volatile("" ::"s"(p.waste_cells), "s"(n_waste), "s"(p.thr_ca), "s"(p.thr_cw), "s"(p.n_thr), "s"(p.rew), "s"(p.done), "s"(p.horizon));
+            else asm volatile("" ::"s"(p.thr_h32[0]), "s"(p.thr_h32[1]), "s"(p.thr_h32[2]), "s"(p.thr_h32[3]), "s"(p.thr_h_always));
+#endif
             hdr = make_uint4(rl(hv, 0), rl(hv, 1), rl(hv, 2), rl(hv, 3));
         } else {
             hdr = a_hdr[e];
