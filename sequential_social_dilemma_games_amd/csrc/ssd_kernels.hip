@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ssd_internal.hpp"
+#include <type_traits>
 
 #ifndef SSD_PIN_EARLY          // (experiment switch: 0 = the prologue's kernel arguments requested where they always were)
 #define SSD_PIN_EARLY 1
@@ -157,9 +158,10 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // up to two agents, so cell coordinates become per-lane arithmetic where the 12-byte form has per-lane CONSTANTS: the renderer's
 // render phase grows from 3 100 to 5 400 cycles and the renderer wave becomes the launch's critical path: 7.6 against 7.03 us.
 __device__ __forceinline__ void store12_wt(uint8_t *base, uint32_t off, u32x3_t d, int wt) {
-    if (wt == 3) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 nt\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
-    else if (wt >= 2) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1 nt\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
-    else if (wt) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+    // (the usual policy first: in the fused kernel's step loop every test in front of it showed, 3.75 -> 3.91 us per step)
+    if (wt == 1) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+    else if (wt == 3) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 nt\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+    else if (wt == 2) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1 nt\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
     else asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
 }
 __device__ __forceinline__ void store16_wt(float *base, uint32_t off, f32x4_t d, int wt) {
@@ -225,22 +227,27 @@ __device__ __forceinline__ void render_views_std(const int lane, const int WP, c
 #pragma unroll
             for (int q = 0; q < 4; ++q) px[u][q] = s_lut[gl[u][q]];
         if (lane_on) {
+            u32x3_t d[kB];
 #pragma unroll
             for (int u = 0; u < kB; ++u) {
-                u32x3_t d;
                 // 4 x (r,g,b) -> 12 bytes with three byte permutes (v_perm_b32: selector bytes 0-3 pick from the second
                 // operand, 4-7 from the first)
-                d.x = __builtin_amdgcn_perm(px[u][1], px[u][0], 0x04020100u);   // r0 g0 b0 r1
-                d.y = __builtin_amdgcn_perm(px[u][2], px[u][1], 0x05040201u);   // g1 b1 r2 g2
-                d.z = __builtin_amdgcn_perm(px[u][3], px[u][2], 0x06050402u);   // b2 r3 g3 b3
-                // (measured with agent blocks 768 bytes apart instead -- every store then covers whole 128-byte lines: 5.30 against
-                // 5.33 us per step; the partly written lines at the blocks' ends are not what bounds the stores)
-#ifdef SSD_EXP_OBS768   // (experiment: agent blocks 768 bytes apart -- every store covers whole 128-byte lines; NOT the output layout)
-                store12_wt(out_env + (size_t)(ag0 + u) * SSD_OBS_STRIDE, off3, d, wt);
-#else
-                store12_wt(out_env + (size_t)(ag0 + u) * VV * 3, off3, d, wt);
-#endif
+                d[u].x = __builtin_amdgcn_perm(px[u][1], px[u][0], 0x04020100u);   // r0 g0 b0 r1
+                d[u].y = __builtin_amdgcn_perm(px[u][2], px[u][1], 0x05040201u);   // g1 b1 r2 g2
+                d[u].z = __builtin_amdgcn_perm(px[u][3], px[u][2], 0x06050402u);   // b2 r3 g3 b3
             }
+            // (measured with agent blocks 768 bytes apart instead -- every store then covers whole 128-byte lines: 5.30 against
+            // 5.33 us per step; the partly written lines at the blocks' ends are not what bounds write-through stores in the
+            // memory-side cache.)  The store policy is wave-uniform: ONE branch per pass of five agents, the five stores of a
+            // policy behind each other (a test per store showed in the fused kernel's step loop: 3.75 -> 3.91 us per step).
+            auto stores = [&](auto policy) {
+#pragma unroll
+                for (int u = 0; u < kB; ++u) store12_wt(out_env + (size_t)(ag0 + u) * SSD_OBS_STRIDE, off3, d[u], decltype(policy)::value);
+            };
+            if (wt == 1) stores(std::integral_constant<int, 1>{});
+            else if (wt == 3) stores(std::integral_constant<int, 3>{});
+            else if (wt == 2) stores(std::integral_constant<int, 2>{});
+            else stores(std::integral_constant<int, 0>{});
         }
     }
 }

@@ -22,3 +22,8 @@ python3 tools/soak_parity.py cleanup48x36 2048 2000 250 chains 2>&1 | grep -v am
 python3 tools/soak_parity.py cleanup48x36 2048 1000 250 actions 2>&1 | grep -v amdgpu.ids | tee $D/soak_cleanup48x36_actions.log | tail -2
 SSD_LIB_PATH=sequential_social_dilemma_games_amd/libssd_hip_testhooks.so SSD_AQL_ALTERNATE=1 python3 tools/soak_parity.py cleanup48x36 2048 1000 250 chains 2>&1 | grep -v amdgpu.ids | tee $D/soak_cleanup48x36_chains_alternate.log | tail -2
 python3 tools/soak_parity.py harvest25x38 4096 1000 250 fused 2>&1 | grep -v amdgpu.ids | tee $D/soak_harvest25x38_fused.log | tail -2
+# ... an observation ring beyond the memory-side cache (21 slots x 4096 envs = 290 MB: non-temporal write-back stores, a release once per
+# round of the ring): EVERY step's observations and rewards compared in their slots after each 20-step call, 50 rounds of the ring
+SOAK_RING=21 SOAK_CHECK_ALL=1 python3 tools/soak_parity.py harvest 4096 1000 20 chains 2>&1 | grep -v amdgpu.ids | tee $D/soak_harvest_ring21_every_step.log | tail -2
+SOAK_RING=21 SOAK_CHECK_ALL=1 python3 tools/soak_parity.py cleanup 4096 600 20 actions 2>&1 | grep -v amdgpu.ids | tee $D/soak_cleanup_ring21_every_step_actions.log | tail -2
+SSD_LIB_PATH=sequential_social_dilemma_games_amd/libssd_hip_testhooks.so SSD_AQL_ALTERNATE=1 SOAK_RING=21 SOAK_CHECK_ALL=1 python3 tools/soak_parity.py harvest 4096 600 20 chains 2>&1 | grep -v amdgpu.ids | tee $D/soak_harvest_ring21_every_step_alternate.log | tail -2
