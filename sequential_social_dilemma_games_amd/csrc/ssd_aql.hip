@@ -602,8 +602,11 @@ uint64_t read_index(const Queue *Q) { return g_api.hsa_queue_load_read_index_sca
 // JOIN: after everything enqueued so far on Q, bump a join counter (`flag_kernarg`: host kernarg block holding the counter's
 // device address); the packet's system-scope release makes the rollout's results visible to everybody.  (The caller's stream
 // waits for the counter with ssd_wait_counter_kernel.)
-void join(Queue *Q, const void *flag_kernarg) {
-    dispatch(Q, Q->flag_kernel, 1, 64, 0, flag_kernarg, /*barrier=*/true, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM);
+void join(Queue *Q, const void *flag_kernarg, bool fences) {
+    // (fences = false: the chain left nothing dirty in a cache -- write-through stores only -- and what waits for the counter is a
+    // kernel on the caller's HIP stream, whose own end-of-kernel release orders the caller's later work)
+    dispatch(Q, Q->flag_kernel, 1, 64, 0, flag_kernarg, /*barrier=*/true, fences ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE,
+             fences ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE);
     ring(Q);
 }
 
@@ -613,7 +616,7 @@ bool join_and_wait(Queue *Q, const void *flag_kernarg) {
     if (!Q->done_signal.handle) return false;
     g_api.hsa_signal_store_screlease(Q->done_signal, 1);
     Q->attach_signal = true;
-    join(Q, flag_kernarg);
+    join(Q, flag_kernarg, true);
     Q->attach_signal = false;
     while (g_api.hsa_signal_wait_scacquire(Q->done_signal, HSA_SIGNAL_CONDITION_LT, 1, 1000000, HSA_WAIT_STATE_BLOCKED) >= 1)
         if (Q->error.load()) return false;
