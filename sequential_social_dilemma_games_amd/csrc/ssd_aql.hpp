@@ -36,7 +36,7 @@ void barrier_and(Queue *q, uint64_t dep_signal_handle);      // the queue waits 
 void ring(Queue *q);                               // doorbell: hand everything written so far to the command processor
 // after everything enqueued on q so far: the counter whose device address `flag_kernarg` (a host_kernarg_alloc block) holds += 1,
 // with a system-scope release; join_and_wait: the host waits until that packet has completed
-void join(Queue *q, const void *flag_kernarg, bool fences = true);
+void join(Queue *q, const void *flag_kernarg);
 bool join_and_wait(Queue *q, const void *flag_kernarg);
 void *host_kernarg_alloc(int device, size_t bytes);   // zeroed host kernarg memory the device can read
 void host_kernarg_free(void *p);

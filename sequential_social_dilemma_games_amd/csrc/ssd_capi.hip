@@ -1018,11 +1018,7 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
         return SSD_OK;
     }
     for (int c = 0; c < chains; ++c) {
-#ifdef SSD_EXP_JOIN_LIGHT   // (experiment: the join packet without fences when the chain's stores were all write-through)
-        ssd::aql::join(A.q[c], A.flag_kernarg, !(coherent && !obs_wb));
-#else
         ssd::aql::join(A.q[c], A.flag_kernarg);
-#endif
         st->last_use[c] = ssd::aql::write_index(A.q[c]);
     }
     A.joins += (unsigned long long)chains;
