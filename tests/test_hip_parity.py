@@ -588,6 +588,79 @@ def test_rollout_actions_matches_the_oracle(game, mode):
     np.testing.assert_array_equal(r2.cpu().numpy(), o_rew)
 
 
+@pytest.mark.parametrize("mode", ["calls", "chains", "fused"])
+@pytest.mark.parametrize("which", ["48x36", "25x18", "25x18_general"])
+def test_cleanup_steps_with_many_shooters(which, mode):
+    """Cleanup with 10 agents of which 4 ... 10 FIRE or CLEAN in the same step (cleanup.py:94-111 through map_env.py:545-649, in
+    action order): more shooters than the 64 / 15 = 4 slots of one parallel beam pass.  Two passes keep the first pass's cells and
+    marks in a second set of registers (overlay patch; in split rollouts a second beam list for the renderer workgroups); nine or
+    ten shooters take three passes and the merged overlay.  Crowded starts (in two thirds of the envs the agents are moved onto
+    ten neighbouring cells, so that beams overlap, hit agents and share waste cells), 40 steps, every step's observations, rewards and state
+    against the oracle -- per-call stepping (plain kernels: the overlay patch), rollout chains (coherent + split kernels: both
+    lists) and the fused kernel; the enlarged map's own kernel, the shipped map's 10-agent kernel, and the general kernel
+    (view_len 6: no map-specific variant)."""
+    import torch
+    amap = K.cleanup_map_48x36() if which == "48x36" else K.CLEANUP_MAP
+    E, N, steps = 192, 10, 40
+    kw = dict(view_len=6) if which == "25x18_general" else {}
+    V = 13 if which == "25x18_general" else 15
+    eng = VecEngine(K.GAME_CLEANUP, amap, num_envs=E, num_agents=N, seed=77, **kw)
+    ora = pyoracle.Oracle(K.GAME_CLEANUP, amap, E, N, G.default_lut(), seed=77, **kw)
+    eng.reset()
+    ora.reset()
+    rng = np.random.RandomState(4242)
+    # crowd the agents: in every env the ten cells nearest to a random cell that are neither wall nor river-side void, in random
+    # order, facing anywhere (two thirds of the envs; the rest keep their spawn points)
+    st = ora.get_state()
+    free = [(r, c) for r in range(len(amap)) for c in range(len(amap[0])) if amap[r][c] != "@"]
+    fr = np.array(free)
+    pos, orient = st["pos"].copy(), st["orient"].copy()
+    for e in range(E):
+        if e % 3 == 2:
+            continue
+        anchor = fr[rng.randint(len(fr))]
+        near = np.argsort(np.abs(fr - anchor).sum(1) + 0.01 * rng.rand(len(fr)))[:N]
+        pos[e] = fr[near[rng.permutation(N)]]
+        orient[e] = rng.randint(0, 4, size=N)
+    eng.set_state(pos=pos, orient=orient)
+    ora.set_state(pos=pos, orient=orient)
+    a_host = np.zeros((steps, E, N), dtype=np.int32)
+    for k in range(steps):
+        for e in range(E):
+            n_sh = 4 + (e + k) % 7                                  # 4 .. 10 shooters
+            a = rng.randint(0, 7, size=N)                           # movers / turners
+            sh = rng.permutation(N)[:n_sh]
+            a[sh] = rng.randint(7, 9, size=n_sh)                    # FIRE or CLEAN
+            a_host[k, e] = a
+    a_dev = torch.from_numpy(a_host).cuda()
+    if mode == "calls":
+        for k in range(steps):
+            o, r, _ = eng.step(a_dev[k])
+            o_obs, o_rew, _ = ora.step(a_host[k])
+            np.testing.assert_array_equal(r.cpu().numpy(), o_rew, err_msg="rewards of step %d" % k)
+            assert np.array_equal(o.cpu().numpy(), o_obs), "observations of step %d differ" % k
+    else:
+        obs = torch.zeros((steps, E, N, V, V, 3), dtype=torch.uint8, device="cuda")
+        rew = torch.zeros((steps, E, N), dtype=torch.int32, device="cuda")
+        done = torch.zeros((steps, E, N), dtype=torch.uint8, device="cuda")
+        eng.set_rollout_chains(2 if mode == "chains" else 1)
+        eng.rollout_actions(a_dev, steps, obs, rew, done, reset_every=0, step0=0, fused=(mode == "fused"))
+        g_obs, g_rew = obs.cpu().numpy(), rew.cpu().numpy()
+        for k in range(steps):
+            o_obs, o_rew, _ = ora.step(a_host[k])
+            np.testing.assert_array_equal(g_rew[k], o_rew, err_msg="rewards of step %d" % k)
+            assert np.array_equal(g_obs[k], o_obs), "observations of step %d differ" % k
+        if which != "25x18_general":
+            path = eng.rollout_path()
+            assert path["fused"] == (mode == "fused"), path
+            assert mode == "fused" or (path["aql"] and path["split"]) or not path["aql"], path
+    a, b = eng.get_state(), ora.get_state()
+    for key in ("world", "pos", "orient", "episode", "t"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert eng.status() == 0
+    eng.close()
+
+
 def test_two_handles_share_the_dispatch_queues():
     """The library's dispatch queues belong to the device, not to a handle: two handles whose rollout calls are enqueued back
     to back follow each other in them.  Both bit-exact."""
