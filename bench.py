@@ -638,6 +638,12 @@ def main():
                                   % (args.steps, "; this rank's figure" if world > 1 else ""),
                          "value": float(E) * n_agents * args.steps / fw, "unit": "agent-env-steps/s per GPU", "us_per_step": fus,
                          "roofline_frac": bytes_env * E / (fus * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                    # (the fused kernel does NOT move the env's state through HBM every step -- 2*H*W grid bytes, N*16 agent bytes and
+                    # the 8-byte header of SURVEY.md 8d's per-step figure stay in LDS / registers: the fraction by the bytes it does
+                    # move is the honest one to set against the headline's)
+                    state_bytes = 2 * eng.H * eng.W + n_agents * 16 + 8
+                    o["bytes_per_env_step_moved"] = bytes_env - state_bytes
+                    o["roofline_frac_by_bytes_moved"] = (bytes_env - state_bytes) * E / (fus * 1e-6) / 1e9 / HBM_PEAK_GBS
                     if args.steps < 1000:
                         lw, _, _ = time_rollout(torch, eng, ring, 1000, 0, step0=args.warmup + args.steps, fused=True)
                         o["long_call_us_per_step"] = lw * 1e6 / 1000
