@@ -78,7 +78,10 @@ class Oracle:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().ssd_oracle_destroy(self._h)
+            try:
+                lib().ssd_oracle_destroy(self._h)
+            except TypeError:                      # (interpreter shutdown: the module's globals are already gone)
+                pass
             self._h = None
 
     def _obs_buf(self):
