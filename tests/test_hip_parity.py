@@ -661,6 +661,53 @@ def test_cleanup_steps_with_many_shooters(which, mode):
     eng.close()
 
 
+def test_per_call_steps_can_be_captured_into_a_hip_graph():
+    """ssd_step with device pointers is ONE kernel launch on the caller's stream and nothing else -- no synchronisation, no
+    allocation, no other stream -- so a training loop may capture it (with its policy) into a HIP graph: torch.cuda.CUDAGraph
+    over 6 steps whose action tensors are rewritten between replays; every replayed step against the oracle.  (The multi-step
+    rollout calls are not capturable: they dispatch through queues of the library's own.)"""
+    import torch
+    E, N, KS = 96, 5, 6
+    eng = VecEngine(K.GAME_CLEANUP, None, num_envs=E, num_agents=N, seed=11)
+    ora = pyoracle.Oracle(K.GAME_CLEANUP, K.CLEANUP_MAP, E, N, G.default_lut(), seed=11)
+    eng.reset()
+    ora.reset()
+    acts = torch.zeros((KS, E, N), dtype=torch.int32, device="cuda")
+    views = [acts[k] for k in range(KS)]
+    outs = [eng.alloc_outputs() for _ in range(KS)]
+    rng = np.random.RandomState(5)
+    side = torch.cuda.Stream()                                          # (torch's capture recipe: warm up on a side stream)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        a = rng.randint(-1, 9, size=(KS, E, N)).astype(np.int32)
+        acts.copy_(torch.from_numpy(a))
+        for k in range(KS):
+            eng.step(views[k], out=outs[k])
+            ora.step(a[k])
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for k in range(KS):
+            eng.step(views[k], out=outs[k])
+    torch.cuda.synchronize()                                            # (capturing executes nothing: the state is the warm-up's)
+    for rep in range(3):
+        a = rng.randint(-1, 9, size=(KS, E, N)).astype(np.int32)
+        acts.copy_(torch.from_numpy(a))
+        g.replay()
+        torch.cuda.synchronize()
+        for k in range(KS):
+            o_obs, o_rew, _ = ora.step(a[k])
+            np.testing.assert_array_equal(outs[k][1].cpu().numpy(), o_rew, err_msg="replay %d, rewards of step %d" % (rep, k))
+            assert np.array_equal(outs[k][0].cpu().numpy(), o_obs), "replay %d, observations of step %d differ" % (rep, k)
+    st_a, st_b = eng.get_state(), ora.get_state()
+    for key in ("world", "pos", "orient", "t"):
+        np.testing.assert_array_equal(st_a[key], st_b[key], err_msg=key)
+    assert eng.status() == 0
+    del g
+    eng.close()
+
+
 def test_two_handles_share_the_dispatch_queues():
     """The library's dispatch queues belong to the device, not to a handle: two handles whose rollout calls are enqueued back
     to back follow each other in them.  Both bit-exact."""
