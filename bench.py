@@ -536,7 +536,7 @@ def main():
                        "enqueue": ("ssd_rollout_random, %d chain(s) of %d envs" % (chains, E // chains)) if use_rollout else "one call per step",
                        "gather": ("one RCCL all-gather of obs and one of rewards per %d steps, overlapped with the next %d steps" % (GR, GR)) if do_gather else False,
                        "parallelism": "env-shard x%d" % world, "rccl_ranks": dist.get_world_size() if dist is not None else 1,
-                       "dispatch": describe(path), "dispatch_per_rank": paths, "dispatch_fallback_ranks": fallback_ranks},
+                       "dispatch": describe(path), "dispatch_timed_call": path, "dispatch_per_rank": paths, "dispatch_fallback_ranks": fallback_ranks},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "ssd::ssd_env_kernel<%d, 0, %s, ...>" % (game, "true" if args.obs_f32 else "false"), "bytes_per_env_step": bytes_env,
