@@ -459,27 +459,38 @@ def main():
     ev0.record()
     ev1.record()
     torch.cuda.synchronize()
-    # the W warm-up steps, issued as a few calls rather than one (every call exercises the whole enqueue path)
-    wchunk = max(4, args.warmup // 4)
-    for w0 in range(0, args.warmup, wchunk):
-        run_steps(w0, min(wchunk, args.warmup - w0))
-    torch.cuda.synchronize()
     # ---- how did every rank's rollout get dispatched?  Known BEFORE anything is timed, reported per rank.  A rank whose HSA agent
     #      could not be matched to its HIP device (device = local_rank != 0 has never run before the first multi-GPU job), or whose
     #      dispatch queues failed their probe, steps through hipLaunchKernel: same results, slower -- never silently. ----
-    my_path = eng.rollout_path() if use_rollout and args.warmup > 0 else None
-    paths = [my_path]
-    if dist is not None:
-        paths = [None] * world
-        dist.all_gather_object(paths, my_path)
-    want_aql = os.environ.get("SSD_AQL", "1") != "0"
-    fallback_ranks = [r for r, p in enumerate(paths) if p is not None and want_aql and not p["aql"]]
-    if fallback_ranks:
-        msg = ("bench.py: rank(s) %s did NOT take the library's own dispatch queues (hipLaunchKernel fallback: SSD_AQL_VERBOSE=1 "
-               "says why); paths: %s" % (fallback_ranks, paths))
-        print("=" * 100 + "\n" + msg + "\n" + "=" * 100, file=sys.stderr)
-        if args.strict_dispatch:
-            raise SystemExit(msg)
+    def exchange_paths():
+        torch.cuda.synchronize()
+        my_path = eng.rollout_path() if use_rollout and args.warmup > 0 else None
+        paths = [my_path]
+        if dist is not None:
+            paths = [None] * world
+            dist.all_gather_object(paths, my_path)
+        want_aql = os.environ.get("SSD_AQL", "1") != "0"
+        fallback_ranks = [r for r, p in enumerate(paths) if p is not None and want_aql and not p["aql"]]
+        if fallback_ranks:
+            msg = ("bench.py: rank(s) %s did NOT take the library's own dispatch queues (hipLaunchKernel fallback: SSD_AQL_VERBOSE=1 "
+                   "says why); paths: %s" % (fallback_ranks, paths))
+            print("=" * 100 + "\n" + msg + "\n" + "=" * 100, file=sys.stderr)
+            if args.strict_dispatch:
+                raise SystemExit(msg)
+        return paths, fallback_ranks
+    # The W warm-up steps, issued as a few calls rather than one (every call exercises the whole enqueue path).  The ranks' dispatch
+    # paths are exchanged after the FIRST of those calls -- an object collective takes milliseconds, and a GPU left idle that long
+    # ahead of the timed region starts it cold (tools/idle_gap_probe.py: a 20-step call 126 us right after other work, 131 after
+    # 1 ms of nothing, 135 - 139 after 5 ms) -- so that the rest of the warm-up does what a warm-up is for: it ends at the opening
+    # barrier.
+    wchunk = max(4, args.warmup // 4)
+    paths, fallback_ranks = None, []
+    for w0 in range(0, args.warmup, wchunk):
+        run_steps(w0, min(wchunk, args.warmup - w0))
+        if paths is None:
+            paths, fallback_ranks = exchange_paths()
+    if paths is None:
+        paths, fallback_ranks = exchange_paths()
     parallel.barrier(dist, local_rank)
     # The opening event is recorded BEFORE the opening synchronize: the timed region then starts on an idle stream, as a rollout
     # call after any synchronize does (an event record just ahead of the call would make the library fork from a "busy" stream:
