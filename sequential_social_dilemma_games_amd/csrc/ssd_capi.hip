@@ -146,6 +146,9 @@ struct ssd_env {
     std::string err;
 };
 
+#ifndef SSD_RING_EVERY            // (experiment switch: 1 = a doorbell per step and chain)
+#define SSD_RING_EVERY 4
+#endif
 namespace {
 
 #define SSD_HIP(env, call)                                                                      \
@@ -1003,7 +1006,14 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
             // (tried: the call's last step rendering itself, its renderer waves in the env's own workgroup behind a barrier -- with
             // a one-slot ring both write the same bytes -- instead of the renderer-only launch: 6.60 against 6.62 us per step of
             // a 20-step call, no gain)
+            // (the doorbell -- an uncached write across the bus, 0.3 - 0.5 us -- after the first two steps, so that the device starts
+            // at once, and then after every fourth: the device needs 5 us per step, the host under 1, it never runs dry; the join
+            // rings for the rest)
+#if SSD_RING_EVERY > 1
+            if (k < 2 || (k % SSD_RING_EVERY) == SSD_RING_EVERY - 1) ssd::aql::ring(A.q[c]);
+#else
             ssd::aql::ring(A.q[c]);
+#endif
         }
         if (split) { o = 1 - o; pending = true; i_prev = i; }
     }
