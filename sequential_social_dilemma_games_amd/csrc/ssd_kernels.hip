@@ -522,7 +522,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // wait for it before it issues the others -- two round trips to memory in a row.  Measured, not reasoned: reading the
         // lanes out after the common wait shortens the wave by 0.2 us (diagnostic build: load phase 1605 -> 1138 cycles) and
         // makes the 4096-env step SLOWER, 5.35 -> 5.53 us (Cleanup 5.79 -> 5.95; no difference at 1024 or 16 384 envs):
-        // with two chains of launches in flight the step is not the wave's latency alone, and the staggered loads suit it)
+        // with two chains of launches in flight the step is not the wave's latency alone, and the staggered loads suit it.
+        // Measured again at the end of round 3, on that round's kernels: 5.51 -> 5.66 us, Harvest 25 x 38 6.00 -> 6.18 -- a launch's
+        // loads are a burst the memory side serves at its own rate, and a wave that asks for everything at once lengthens it)
         // kPre (Cleanup, the map-specific coherent step kernels).  Cleanup's spawn pass starts with a DEPENDENT fetch: the two
         // thresholds of the current waste count (cleanup.py:156-171 through the host's tables), a scalar load that can only go
         // out once the beams have said how many cells they cleaned -- a round trip to L2 in the middle of the wave, with nothing
