@@ -483,6 +483,12 @@ def main():
     # ahead of the timed region starts it cold (tools/idle_gap_probe.py: a 20-step call 126 us right after other work, 131 after
     # 1 ms of nothing, 135 - 139 after 5 ms) -- so that the rest of the warm-up does what a warm-up is for: it ends at the opening
     # barrier.
+    # (and no collector pause in or just ahead of a timed region of ~130 us -- the ranks report the MAX of theirs: a collection right
+    # in front of it cost 30 us, 8.0 against 6.6 us per step: host caches and device both cold; so: collect NOW, before the warm-up,
+    # and keep the collector off until the timed steps are done)
+    import gc
+    gc.collect()
+    gc.disable()
     wchunk = max(4, args.warmup // 4)
     paths, fallback_ranks = None, []
     for w0 in range(0, args.warmup, wchunk):
@@ -504,6 +510,7 @@ def main():
     enq = time.perf_counter() - t0                 # host time to enqueue the K steps (must stay below the device time)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0                # this rank's K steps, start barrier to its own completion; MAX over ranks below
+    gc.enable()
     parallel.barrier(dist, local_rank)             # (the closing barrier: everybody is done before anybody reports; its own
     torch.cuda.synchronize()                       #  latency, ~1 ms of RCCL, is not part of any rank's K steps)
     dev_ms = ev0.elapsed_time(ev1)
