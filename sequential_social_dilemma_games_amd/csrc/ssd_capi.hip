@@ -1010,7 +1010,7 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
             // at once, and then after every fourth: the device needs 5 us per step, the host under 1, it never runs dry; the join
             // rings for the rest)
 #if SSD_RING_EVERY > 1
-            if (k < 2 || (k % SSD_RING_EVERY) == SSD_RING_EVERY - 1) ssd::aql::ring(A.q[c]);
+            if (!coherent || k < 2 || (k % SSD_RING_EVERY) == SSD_RING_EVERY - 1) ssd::aql::ring(A.q[c]);   // (large launches: every step, as ever)
 #else
             ssd::aql::ring(A.q[c]);
 #endif
