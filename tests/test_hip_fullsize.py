@@ -74,22 +74,28 @@ def test_rollout_dispatch_modes_when_envs_change_xcd(game, how, knobs):
     assert r.returncode == 0 and "soak ok" in out, out[-2000:]
 
 
-@pytest.mark.parametrize("how,hooks", [("chains", True), ("chains", False), ("actions", False), ("fused", False)])
+@pytest.mark.parametrize("how,hooks", [("chains", True), ("chains", False), ("actions", False), ("fused", False),
+                                       ("chains", "SSD_AQL=0"), ("chains", "SSD_AQL_COHERENT=0")])
 def test_output_rings_beyond_the_memory_side_cache(how, hooks):
     """An observation ring of more than 232 MB (here 21 slots x 4096 envs = 290 MB) is written with non-temporal write-BACK
     stores (ssd_kernels.hip select(): the partly covered sectors at the ends of the agents' 675-byte blocks merge in L2), made
     safe by an agent-scope release on one launch per round of the ring and the call's closing release.  100 steps in 20-step
     calls -- the ring goes round four times -- every step's observations and rewards compared with the oracle's in its slot
     after the call that wrote it.  With the test-hook library's SSD_AQL_ALTERNATE the env -> workgroup -> XCD mapping changes
-    from every launch to the next, and 21 being odd, a slot's bytes are rewritten through the OTHER mapping a round later."""
+    from every launch to the next, and 21 being odd, a slot's bytes are rewritten through the OTHER mapping a round later.
+    Also through the hipLaunchKernel path (SSD_AQL=0) and with the plain kernels behind agent-scope fences (SSD_AQL_COHERENT=0),
+    whose launches release after every step."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     for k in ("SSD_AQL", "SSD_AQL_ALTERNATE", "SSD_AQL_ALWAYS_FORK", "SSD_AQL_SPLIT", "SSD_AQL_COHERENT", "SSD_LIB_PATH"):
         env.pop(k, None)
-    if hooks:
+    if hooks is True:
         env.update(SSD_AQL_ALTERNATE="1", SSD_LIB_PATH=HOOKS_LIB)
+    elif hooks:                                             # (a product knob: the hipLaunchKernel path / the plain kernels behind fences)
+        k, v = hooks.split("=")
+        env[k] = v
     env.update(SOAK_RING="21", SOAK_CHECK_ALL="1")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_parity.py"), "harvest", "4096", "100", "20", how],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
