@@ -221,8 +221,7 @@ def config_leg(torch, name, E, steps=400, warmup=50, obs_f32=False):
 def policy_step_leg(torch, game, amap, n_agents, E, steps=300, K=20):
     """The step with CALLER-SUPPLIED actions: what the reference's callers do (visuallizer_rllib.py:121-153; RLlib's sampler behind
     train_baseline.py:71-81).  (a) SSDVectorEnv.step(device action tensor): one Python call, one hipLaunchKernel of the plain
-    step kernel and, when the horizon comes, one reset launch per step; (b) the same step dispatched through the library's chains
-    (SSD_STEP_CHAINS); (c) ssd_rollout_actions: chunks of K steps per call (synchronised after every call, as the driver's
+    step kernel and, when the horizon comes, one reset launch per step; (b) the engine's own step call; (c) ssd_rollout_actions: chunks of K steps per call (synchronised after every call, as the driver's
     K-step region is) and one long call.  us per 4096-env step each; actions are a fixed random tensor on the device."""
     from sequential_social_dilemma_games_amd.vector_env import SSDVectorEnv
     na = 8 if game == 0 else 9
@@ -247,8 +246,6 @@ def policy_step_leg(torch, game, amap, n_agents, E, steps=300, K=20):
             return (time.perf_counter() - t0) * 1e6 / n
         out["vector_env_step_us"] = per_call(lambda i: venv.step(acts[i % K]), steps)
         out["engine_step_us"] = per_call(lambda i: eng.step(acts[i % K], out=venv._out), steps)
-        out["engine_step_via_chains_us"] = per_call(lambda i: eng.step(acts[i % K], out=venv._out, chains=True), steps)
-        out["engine_step_via_chains_dispatch"] = eng.rollout_path()
         ring = tuple(t.unsqueeze(0) for t in venv._out)
         eng.set_rollout_chains(0)
         calls = max(3, steps // K)
@@ -378,6 +375,8 @@ def main():
     eng, start, count = parallel.make_sharded_engine(game, amap, world * E, n_agents, rank, world,
                                                      local_rank=local_rank, seed=0)
     assert (start, count) == (rank * E, E)
+    # (the engine steps on the rank's own device -- a rank that silently stepped on device 0 would still produce a figure)
+    assert eng.device == local_rank == torch.cuda.current_device(), (eng.device, local_rank, torch.cuda.current_device())
     out = eng.alloc_outputs(float32=args.obs_f32)
     do_gather = bool(args.gather and dist is not None and not rehearsal)
     GR = max(1, args.gather_steps)                 # gather modes: steps per collective (one RCCL collective moves GR steps' outputs)
@@ -465,12 +464,21 @@ def main():
     def exchange_paths():
         torch.cuda.synchronize()
         my_path = eng.rollout_path() if use_rollout and args.warmup > 0 else None
+        if my_path is not None:
+            # which physical device this rank stepped on (what the library matched its HSA agent against): eight ranks must show
+            # eight different addresses, and "agent_match" how each was found
+            pr = torch.cuda.get_device_properties(local_rank)
+            my_path = dict(my_path, rank=rank, device=eng.device,
+                           pci="%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)))
         paths = [my_path]
         if dist is not None:
             paths = [None] * world
             dist.all_gather_object(paths, my_path)
         want_aql = os.environ.get("SSD_AQL", "1") != "0"
         fallback_ranks = [r for r, p in enumerate(paths) if p is not None and want_aql and not p["aql"]]
+        pcis = [p["pci"] for p in paths if p is not None]
+        if not rehearsal and len(set(pcis)) != len(pcis):
+            raise SystemExit("bench.py: two ranks stepped on the same physical device: %s" % (paths,))
         if fallback_ranks:
             msg = ("bench.py: rank(s) %s did NOT take the library's own dispatch queues (hipLaunchKernel fallback: SSD_AQL_VERBOSE=1 "
                    "says why); paths: %s" % (fallback_ranks, paths))

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SSD_ABI_VERSION 2   /* 2: ssd_rollout_actions, SSD_STEP_CHAINS, ssd_profiler_attached; SSD_ROLLOUT_PIPELINED removed */
+#define SSD_ABI_VERSION 3   /* 3: SSD_ROLLOUT_AUTO; SSD_STEP_CHAINS removed.  2: ssd_rollout_actions, ssd_profiler_attached; SSD_ROLLOUT_PIPELINED removed */
 
 enum {
     SSD_OK = 0,
@@ -63,11 +63,13 @@ enum {
     /* (1u << 5 was SSD_ROLLOUT_PIPELINED, rounds 1-2: launches of consecutive steps overlapped through per-env pass counters.
        It bought nothing once the library dispatched through its own queues -- 4.44 against 4.50 us per step at 2048 envs -- and
        was the one mode in which kernels waited on other kernels' flags: removed.  The bit is ignored.) */
-    SSD_STEP_CHAINS = 1u << 6, /* ssd_step only: dispatch the step the way a one-step ssd_rollout_actions call is dispatched -- env
-                                ranges stepped concurrently through the library's own queues, forked from and joined into `stream`.
-                                Device pointers, order == NULL, no SSD_AUTO_RESET.  Same results as the plain call.  Whether it
-                                pays depends on the batch: a single launch has no chain of dependent launches to hide, and the
-                                fork / join cost ~20 us per call (bench.py: policy_step) */
+    /* (1u << 6 was SSD_STEP_CHAINS, ABI 2: ssd_step dispatched like a one-step ssd_rollout_actions call.  Measured at the named
+       batch -- 4096 envs -- it cost 21.7 us per call against 7.3 for the plain launch: a single launch has no chain of dependent
+       launches to hide, and the fork / join cost more than two concurrent half-launches save.  Removed; the bit is ignored.) */
+    SSD_ROLLOUT_AUTO = 1u << 7, /* ssd_rollout_random / ssd_rollout_actions: let the library pick the form of the call.  uint8
+                                observations, index action order and n_steps >= 2 take the fused kernel (SSD_ROLLOUT_FUSED: 3.5 us per
+                                4096-env step against 5.4 through the chains); anything else is dispatched as without the flag.
+                                Same results either way; ssd_rollout_path() says which form ran. */
     SSD_OBS_F32 = 1u << 2    /* obs points at float32 [E,N,V,V,3] instead of uint8: the normalisation of map_env.py:199
                                 fused into the kernel (4x the observation bytes; a separate, slower mode) */
 };
@@ -79,7 +81,11 @@ enum {
     SSD_ST_MOVE_LOOKUP = 1u << 2, /* agent_by_pos lookup miss (would be a KeyError at map_env.py:506) */
     SSD_ST_WAIT_TIMEOUT = 1u << 3 /* a rollout call's stream-side wait for the library's queues gave up (seconds: the queues' kernels
                                      never ran -- e.g. a tool that runs kernels one at a time, attached in a way the library did not
-                                     notice); the call's outputs are not in place.  See SSD_AQL_SYNC below */
+                                     notice); the call's outputs are not in place.  See SSD_AQL_SYNC below.  The condition is STICKY:
+                                     the handle's next rollout call, or ssd_synchronize, drains the library's queues on the host
+                                     (bounded), returns SSD_E_DEVICE once, and the handle steps through hipLaunchKernel from then
+                                     on.  Until one of them has returned, the timed-out call's buffers must not be freed or reused:
+                                     its launches may still be writing them */
 };
 
 typedef struct ssd_env ssd_env;
@@ -163,7 +169,7 @@ int ssd_rollout_actions(ssd_env *env, const int32_t *actions, const uint8_t *ord
                         int32_t reset_every, int32_t step0, void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags,
                         void *stream);
 
-/* How the last rollout call (ssd_rollout_random / ssd_rollout_actions / ssd_step with SSD_STEP_CHAINS) of the handle was
+/* How the last rollout call (ssd_rollout_random / ssd_rollout_actions) of the handle was
  * dispatched (a bit mask; 0 before the first call):
  *   SSD_PATH_AQL       the launches were written as AQL packets into the library's own queues (else: hipLaunchKernel)
  *   SSD_PATH_COHERENT  ... with the kernel variant that needs no cache write-back between a chain's launches
@@ -173,6 +179,8 @@ int ssd_rollout_actions(ssd_env *env, const int32_t *actions, const uint8_t *ord
  *   SSD_PATH_FORKED    ... behind a fork from `stream`, which had work pending when the call came
  *   SSD_PATH_QUEUE_DROPPED  a dispatch queue of the device's pool failed its probe and was destroyed again (the rule below)
  *   bits 8..11         number of chains        bits 12..14  dispatch queues the device's pool has settled on
+ *   bits 16..17        how the library found the HSA agent of the handle's HIP device: 1 PCI address, 2 UUID, 3 ordinal (cross-
+ *                      checked by architecture and compute-unit count); 0: not at all -- no dispatch path of its own on this device
  * So that a caller (a test, a benchmark) can tell a silent fallback from the path it meant to measure. */
 enum { SSD_PATH_AQL = 1, SSD_PATH_COHERENT = 2, SSD_PATH_SPLIT = 4, SSD_PATH_FUSED = 8, SSD_PATH_SYNC = 16, SSD_PATH_QUEUE_DROPPED = 32,
        SSD_PATH_FORKED = 64 };

@@ -12,10 +12,10 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSD_LIB_PATH") or os.path.join(_PKG, "libssd_hip.so")
 
 SSD_OK, SSD_E_INVALID, SSD_E_DEVICE, SSD_E_NOMEM, SSD_E_STATE = 0, -1, -2, -3, -4
-SSD_HOST_PTRS, SSD_NO_ROTATE, SSD_OBS_F32, SSD_ROLLOUT_FUSED, SSD_AUTO_RESET, SSD_STEP_CHAINS = 1, 2, 4, 8, 16, 64
+SSD_HOST_PTRS, SSD_NO_ROTATE, SSD_OBS_F32, SSD_ROLLOUT_FUSED, SSD_AUTO_RESET, SSD_ROLLOUT_AUTO = 1, 2, 4, 8, 16, 128
 SSD_PATH_AQL, SSD_PATH_COHERENT, SSD_PATH_SPLIT, SSD_PATH_FUSED, SSD_PATH_SYNC, SSD_PATH_QUEUE_DROPPED, SSD_PATH_FORKED = 1, 2, 4, 8, 16, 32, 64
 SSD_ST_BAD_ACTION, SSD_ST_NO_SPAWN, SSD_ST_MOVE_LOOKUP, SSD_ST_WAIT_TIMEOUT = 1, 2, 4, 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/ssd.h declares
 SYMBOLS = ("ssd_create", "ssd_destroy", "ssd_reset", "ssd_step", "ssd_step_random", "ssd_rollout_random", "ssd_rollout_actions", "ssd_rollout_path", "ssd_set_rollout_chains",

@@ -46,6 +46,7 @@
 
 #include "ssd_internal.hpp"
 #include "ssd_aql.hpp"
+#include "ssd_agent_match.hpp"
 
 extern "C" const unsigned char ssd_kernels_bundle[];        // ssd_codeobj.S: the clang offload bundle of ssd_kernels.o
 extern "C" const unsigned char ssd_kernels_bundle_end[];
@@ -99,6 +100,8 @@ struct DeviceCtx {
     int pool_cap = kPoolSlots;                            // shrinks when a new queue fails its probe
     int dropped = 0;                                      // queues destroyed again by the probe
     const char *matched_by = "";                          // how the HSA agent was matched to the HIP device
+    std::string agent_pci;                                // ... and that agent's PCI address (domain:bus:device.function)
+    long long *hip_scratch = nullptr;                     // device memory (THIS device's) the probe's HIP burst writes
 };
 std::mutex g_mu;
 bool g_api_tried = false, g_api_ok = false;
@@ -127,27 +130,24 @@ bool load_api() {
     return true;
 }
 
-struct AgentSearch {
-    uint32_t want_bdf, want_domain; bool found; hsa_agent_t gpu; bool have_cpu; hsa_agent_t cpu;
-    // second and third chance: the agent whose UUID string ("GPU-<16 hex digits>") HIP reports for the device; the n-th GPU agent
-    char want_uuid[24]; bool found_uuid; hsa_agent_t gpu_uuid;
-    int want_ordinal, seen_gpus; bool found_ordinal; hsa_agent_t gpu_ordinal;
-};
+// Every HSA agent as a plain record (ssd_agent_match.hpp decides on those), with its handle beside it.
+struct AgentList { std::vector<AgentRecord> rec; std::vector<hsa_agent_t> handle; };
 hsa_status_t agent_cb(hsa_agent_t a, void *data) {
-    auto *s = static_cast<AgentSearch *>(data);
+    auto *L = static_cast<AgentList *>(data);
+    AgentRecord r;
     hsa_device_type_t type;
     if (g_api.hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &type) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
-    if (type == HSA_DEVICE_TYPE_CPU) { if (!s->have_cpu) { s->cpu = a; s->have_cpu = true; } return HSA_STATUS_SUCCESS; }
-    if (type != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
-    uint32_t bdf = 0, domain = 0;
-    g_api.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
-    g_api.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
-    if (!s->found && bdf == s->want_bdf && domain == s->want_domain) { s->gpu = a; s->found = true; }
-    char uuid[64] = {};
-    if (!s->found_uuid && s->want_uuid[0] && g_api.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_UUID, uuid) == HSA_STATUS_SUCCESS &&
-        std::strncmp(uuid, s->want_uuid, sizeof(s->want_uuid)) == 0) { s->gpu_uuid = a; s->found_uuid = true; }
-    if (!s->found_ordinal && s->seen_gpus == s->want_ordinal) { s->gpu_ordinal = a; s->found_ordinal = true; }
-    s->seen_gpus++;
+    r.type = type == HSA_DEVICE_TYPE_CPU ? kAgentCpu : type == HSA_DEVICE_TYPE_GPU ? kAgentGpu : kAgentOther;
+    if (r.type == kAgentGpu) {
+        r.has_bdf = g_api.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &r.bdf) == HSA_STATUS_SUCCESS &&
+                    g_api.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &r.domain) == HSA_STATUS_SUCCESS;
+        char uuid[64] = {};
+        if (g_api.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_UUID, uuid) == HSA_STATUS_SUCCESS) std::memcpy(r.uuid, uuid, sizeof r.uuid);
+        char name[64] = {};
+        if (g_api.hsa_agent_get_info(a, HSA_AGENT_INFO_NAME, name) == HSA_STATUS_SUCCESS) { std::memcpy(r.name, name, sizeof r.name - 1); }
+        (void)g_api.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_COMPUTE_UNIT_COUNT, &r.cu_count);
+    }
+    L->rec.push_back(r); L->handle.push_back(a);
     return HSA_STATUS_SUCCESS;
 }
 hsa_status_t pool_cb(hsa_amd_memory_pool_t pool, void *data) {
@@ -201,35 +201,41 @@ DeviceCtx *device_ctx(int device) {
     if (off) { c.why = "SSD_AQL=0"; return nullptr; }
     if (!load_api()) { c.why = "HSA runtime unavailable"; return nullptr; }
     auto fail = [&](const std::string &m) -> DeviceCtx * { c.why = m; say(m); return nullptr; };
-    // the HSA agent behind HIP device `device`: same PCI function
-    int dom = 0, bus = 0, dev = 0;
-    if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, device) != hipSuccess ||
-        hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, device) != hipSuccess ||
-        hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, device) != hipSuccess)
-        return fail("cannot read the device's PCI address");
-    AgentSearch s{};
-    s.want_domain = (uint32_t)dom;
-    {   // (HIP's 16-byte device uuid is the hex digits of the HSA agent's "GPU-<hex>" string)
-        hipUUID u{};
+    // the HSA agent behind HIP device `device` (the rule and its tests: ssd_agent_match.hpp, tests/test_agent_match_cpu.py)
+    DeviceRecord d;
+    d.ordinal = device;
+    {
+        int dom = 0, bus = 0, dev = 0;
+        d.has_pci = hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, device) == hipSuccess &&
+                    hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, device) == hipSuccess &&
+                    hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, device) == hipSuccess;
+        d.domain = (uint32_t)dom; d.bus = (uint32_t)bus; d.dev = (uint32_t)dev;
+        hipUUID u{};                                  // (HIP's 16-byte device uuid is the hex digits of the HSA agent's "GPU-<hex>" string)
         if (hipDeviceGetUuid(&u, device) == hipSuccess && u.bytes[0]) {
-            std::memcpy(s.want_uuid, "GPU-", 4);
-            std::memcpy(s.want_uuid + 4, u.bytes, 16);
+            std::memcpy(d.uuid, "GPU-", 4);
+            std::memcpy(d.uuid + 4, u.bytes, 16);
+        }
+        hipDeviceProp_t prop{};
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+            std::strncpy(d.arch, prop.gcnArchName, sizeof d.arch - 1);
+            d.cu_count = (uint32_t)prop.multiProcessorCount;
         }
         (void)hipGetLastError();
         // (the n-th GPU agent is the HIP device n only while nothing filters or reorders the devices HIP shows)
-        const bool filtered = getenv("HIP_VISIBLE_DEVICES") || getenv("CUDA_VISIBLE_DEVICES");
-        s.want_ordinal = filtered ? -1 : device;
+        d.filtered = getenv("HIP_VISIBLE_DEVICES") || getenv("CUDA_VISIBLE_DEVICES") || getenv("ROCR_VISIBLE_DEVICES");
     }
-    for (uint32_t fn = 0; fn < 8 && !s.found; ++fn) {       // BDFID = bus << 8 | device << 3 | function
-        s.want_bdf = ((uint32_t)bus << 8) | ((uint32_t)dev << 3) | fn;
-        s.have_cpu = false; s.seen_gpus = 0;
-        g_api.hsa_iterate_agents(agent_cb, &s);
+    AgentList agents;
+    g_api.hsa_iterate_agents(agent_cb, &agents);
+    const AgentMatch m = match_agent(agents.rec, d);
+    if (m.gpu < 0 || m.cpu < 0) return fail(m.why);
+    c.matched_by = m.by;
+    c.gpu = agents.handle[(size_t)m.gpu]; c.cpu = agents.handle[(size_t)m.cpu];
+    {   // what bench.py prints per rank: the PCI address of the device the rank steps on, and the agent's
+        char buf[96];
+        std::snprintf(buf, sizeof buf, "%04x:%02x:%02x.%x", agents.rec[(size_t)m.gpu].domain, agents.rec[(size_t)m.gpu].bdf >> 8,
+                      (agents.rec[(size_t)m.gpu].bdf >> 3) & 31u, agents.rec[(size_t)m.gpu].bdf & 7u);
+        c.agent_pci = buf;
     }
-    c.matched_by = "PCI address";
-    if (!s.found && s.found_uuid) { s.gpu = s.gpu_uuid; s.found = true; c.matched_by = "UUID"; }
-    if (!s.found && s.found_ordinal) { s.gpu = s.gpu_ordinal; s.found = true; c.matched_by = "ordinal"; }
-    if (!s.found || !s.have_cpu) return fail("no HSA agent matches HIP device " + std::to_string(device) + " (PCI address, UUID, ordinal)");
-    c.gpu = s.gpu; c.cpu = s.cpu;
     c.host_kernarg_pool.handle = 0;
     g_api.hsa_amd_agent_iterate_memory_pools(c.cpu, pool_cb, &c.host_kernarg_pool);
     if (!c.host_kernarg_pool.handle) return fail("no kernarg memory pool");
@@ -245,7 +251,7 @@ DeviceCtx *device_ctx(int device) {
     st = g_api.hsa_executable_freeze(c.exe, nullptr);
     if (st != HSA_STATUS_SUCCESS) return fail("hsa_executable_freeze failed");
     c.ok = true;
-    say("device " + std::to_string(device) + ": own AQL dispatch path ready (HSA agent matched by " + c.matched_by + ")");
+    say("device " + std::to_string(device) + ": own AQL dispatch path ready (HSA agent " + c.agent_pci + " matched by " + c.matched_by + ")");
     return &c;
 }
 
@@ -413,14 +419,24 @@ static double concurrent_burst_us(DeviceCtx *c, Queue *const *qs, int nq, int n)
         for (int i = 0; i < nq; ++i) dispatch(qs[i], qs[i]->flag_kernel, 1, 64, 0, c->probe_kernarg, true, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE);
     for (int i = 0; i < nq; ++i) ring(qs[i]);
     c->probe_count += (unsigned long long)nq * (unsigned long long)n;
-    launch_wait_counter_kernel(c->probe_counter, c->probe_count, static_cast<const uint32_t *>(c->abort_dev), 100000000ull /* 1 s */, nullptr, nullptr);
+    launch_wait_counter_kernel(c->probe_counter, c->probe_count, static_cast<const uint32_t *>(c->abort_dev), 100000000ull /* 1 s */, nullptr, nullptr, nullptr);
     if (hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipGetLastError(); return -1; }
     return now_us() - t0;
 }
 // A burst of one-wave HIP launches on the null stream + synchronize; microseconds, < 0 on failure.
-static double hip_burst_us(int n) {
-    static long long *scratch = [] { void *ptr = nullptr; if (hipMalloc(&ptr, 8) != hipSuccess) ptr = nullptr; return static_cast<long long *>(ptr); }();
-    if (!scratch) return -1;
+// (the word the burst's kernels write belongs to the context's own device -- ADVICE r03: one process-wide word made a second
+// device's probe store into the first device's memory, a fault without peer access and a burst timed over xGMI with it)
+static double hip_burst_us(DeviceCtx *c, int n) {
+    if (!c->hip_scratch) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != c->device) { (void)hipGetLastError(); return -1; }   // (the caller is on the handle's device)
+        void *ptr = nullptr;
+        if (hipMalloc(&ptr, 8) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, ptr) != hipSuccess || at.device != c->device) { (void)hipGetLastError(); (void)hipFree(ptr); return -1; }
+        c->hip_scratch = static_cast<long long *>(ptr);
+    }
+    long long *scratch = c->hip_scratch;
     const double t0 = now_us();
     for (int i = 0; i < n; ++i) launch_signal_kernel(scratch, nullptr);
     if (hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipGetLastError(); return -1; }
@@ -451,7 +467,7 @@ static bool probe_pool_queue(DeviceCtx *c, Queue *Q, int index) {
     (void)concurrent_burst_us(c, qs, nq, 2);              // (first dispatches of a new queue: not timed)
     double qv[kBurstReps], hv[kBurstReps];
     for (double &x : qv) x = concurrent_burst_us(c, qs, nq, kBurst);
-    for (double &x : hv) x = hip_burst_us(kBurst);
+    for (double &x : hv) x = hip_burst_us(c, kBurst);
     std::sort(qv, qv + kBurstReps); std::sort(hv, hv + kBurstReps);
     const double q_us = qv[0] < 0 ? -1 : qv[kBurstReps / 2], h_us = hv[0] < 0 ? -1 : hv[kBurstReps / 2];
     c->q_burst_last_us = q_us; c->hip_burst_last_us = h_us;
@@ -496,9 +512,9 @@ Queue *pool_queue(int device, int index) {
         }
         (void)hipGetLastError();
         // what HIP launches cost in this process before the library holds any queue of its own
-        (void)hip_burst_us(2);
+        (void)hip_burst_us(c, 2);
         double v[kBurstReps];
-        for (double &x : v) x = hip_burst_us(kBurst);
+        for (double &x : v) x = hip_burst_us(c, kBurst);
         std::sort(v, v + kBurstReps);
         c->hip_burst_base_us = v[0] < 0 ? 0 : v[kBurstReps / 2];
     }
@@ -520,10 +536,13 @@ Queue *pool_queue(int device, int index) {
     c->pool[index] = Q;
     return Q;
 }
-// bits for ssd_rollout_path(): the size the pool settled on (<< 12) | "a queue failed its probe and was destroyed" (32)
+// bits for ssd_rollout_path(): the size the pool settled on (<< 12) | "a queue failed its probe and was destroyed" (32) | how the
+// HSA agent was matched to the HIP device (<< 16: 1 PCI address, 2 UUID, 3 ordinal; 0: no agent, no own dispatch path)
 int pool_report(int device) {
     if (device < 0 || device >= 64) return 0;
-    return (pool_size(device) << 12) | (g_dev[device].dropped ? 32 : 0);
+    const char *by = g_dev[device].matched_by;
+    const int how = !g_dev[device].ok ? 0 : by[0] == 'P' ? 1 : by[0] == 'U' ? 2 : by[0] == 'o' ? 3 : 0;
+    return (pool_size(device) << 12) | (g_dev[device].dropped ? 32 : 0) | (how << 16);
 }
 void probe_figures(int device, double out[4]) {
     const DeviceCtx &c = g_dev[device];
@@ -611,14 +630,18 @@ void join(Queue *Q, const void *flag_kernarg) {
 
 // Synchronous join (SSD_AQL_SYNC=1: profiling with serialised kernels, where a kernel that waits for another queue's kernel
 // would wait forever): the join packet carries a completion signal and the HOST waits for it.
-bool join_and_wait(Queue *Q, const void *flag_kernarg) {
+// (max_seconds > 0: give up after that long -- the drain behind a join that timed out must not hang on a queue that is stuck)
+bool join_and_wait(Queue *Q, const void *flag_kernarg, double max_seconds) {
     if (!Q->done_signal.handle) return false;
     g_api.hsa_signal_store_screlease(Q->done_signal, 1);
     Q->attach_signal = true;
     join(Q, flag_kernarg);
     Q->attach_signal = false;
-    while (g_api.hsa_signal_wait_scacquire(Q->done_signal, HSA_SIGNAL_CONDITION_LT, 1, 1000000, HSA_WAIT_STATE_BLOCKED) >= 1)
+    const double t0 = now_us();
+    while (g_api.hsa_signal_wait_scacquire(Q->done_signal, HSA_SIGNAL_CONDITION_LT, 1, 1000000, HSA_WAIT_STATE_BLOCKED) >= 1) {
         if (Q->error.load()) return false;
+        if (max_seconds > 0 && now_us() - t0 > max_seconds * 1e6) return false;
+    }
     return true;
 }
 

@@ -37,7 +37,7 @@ void ring(Queue *q);                               // doorbell: hand everything 
 // after everything enqueued on q so far: the counter whose device address `flag_kernarg` (a host_kernarg_alloc block) holds += 1,
 // with a system-scope release; join_and_wait: the host waits until that packet has completed
 void join(Queue *q, const void *flag_kernarg);
-bool join_and_wait(Queue *q, const void *flag_kernarg);
+bool join_and_wait(Queue *q, const void *flag_kernarg, double max_seconds = 0);   // max_seconds > 0: false when the wait exceeds it
 void *host_kernarg_alloc(int device, size_t bytes);   // zeroed host kernarg memory the device can read
 void host_kernarg_free(void *p);
 const uint32_t *abort_flag_dev(int device);        // device address of the word that is set when a queue of the device fails

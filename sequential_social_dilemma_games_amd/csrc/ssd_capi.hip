@@ -72,6 +72,9 @@ struct AqlState {
     unsigned long long *join_counter = nullptr;     // device memory: += 1 by every chain's last packet of a call
     unsigned long long joins = 0;                   // value it reaches when everything enqueued so far is done
     void *flag_kernarg = nullptr;                   // host kernarg block: the flag kernel's argument (= join_counter)
+    // the join's stream-side wait gave up (SSD_ST_WAIT_TIMEOUT): set by that kernel in host memory, so that the handle's next call
+    // sees it without a device round trip; STICKY until ssd_synchronize or the next rollout call has reported it (after_timeout)
+    uint32_t *timed_out_host = nullptr, *timed_out_dev = nullptr;
     struct Key {
         const void *obs = nullptr, *rew = nullptr, *done = nullptr;
         int32_t ring = 0, f32 = 0, num_actions = 0, chains = 0, horizon = 0, coherent = 0, split = 0;
@@ -524,11 +527,6 @@ int ssd_step(ssd_env *env, const int32_t *actions, const uint8_t *order, void *o
     if (!env) return SSD_E_INVALID;
     if (!actions && env->N > 0) { env->err = "actions is null"; return SSD_E_INVALID; }   // an env without agents has no actions
     if ((flags & SSD_AUTO_RESET) && (flags & SSD_OBS_F32)) { env->err = "an auto-reset step writes uint8 observations"; return SSD_E_INVALID; }
-    if (flags & SSD_STEP_CHAINS) {
-        // the step as a one-step ssd_rollout_actions call: env ranges stepped concurrently through the library's own queues
-        if ((flags & (SSD_HOST_PTRS | SSD_AUTO_RESET)) || order) { env->err = "a step through the rollout chains takes device pointers, index action order and no auto-reset"; return SSD_E_INVALID; }
-        return rollout(env, actions, nullptr, 1, 0, 1, 0, 0, obs, rew, done, 1, flags & SSD_OBS_F32, stream);
-    }
     return run(env, (flags & SSD_AUTO_RESET) ? ssd::kModeStepAuto : ssd::kModeStep, actions, order, nullptr, 0, nullptr, obs, rew, done, 1,
                flags, stream);
 }
@@ -685,6 +683,32 @@ static void aql_drain(ssd_env *env) {
     }
 }
 
+// A wait of one of the handle's rollout calls timed out: the call had returned SSD_OK long before, the caller's
+// stream went on, and the chains' packets may still be running and writing obs / rew / done and the state pair.  The first API
+// call that notices -- the next rollout call, ssd_synchronize -- drains the library's queues on the host (bounded: a queue that
+// is stuck for good is left alone), takes the handle off the library's own dispatch path (later calls issue the same launches
+// through hipLaunchKernel) and reports SSD_E_DEVICE once.  Until then the call's buffers must not be freed or reused.
+static int after_timeout(ssd_env *env) {
+    if (!env->aql || !env->aql->timed_out_host) return SSD_OK;
+    AqlState &A = *env->aql;
+    if (!__atomic_load_n(A.timed_out_host, __ATOMIC_ACQUIRE)) return SSD_OK;
+    bool drained = true;
+    if (A.joins && A.flag_kernarg) {
+        std::lock_guard<std::mutex> enqueue_lock(ssd::aql::enqueue_mutex(env->device));
+        for (int c = 0; c < A.nq; ++c) {
+            if (!A.q[c] || ssd::aql::queue_failed(A.q[c])) continue;
+            if (ssd::aql::join_and_wait(A.q[c], A.flag_kernarg, 10.0)) A.joins += 1; else drained = false;
+        }
+    }
+    __atomic_store_n(A.timed_out_host, 0u, __ATOMIC_RELEASE);
+    A.ok = false;
+    env->err = drained ? "a rollout call's wait for the library's dispatch queues timed out (SSD_ST_WAIT_TIMEOUT): its outputs may be incomplete; "
+                         "the queues have been drained and the handle now steps through hipLaunchKernel"
+                       : "a rollout call's wait for the library's dispatch queues timed out (SSD_ST_WAIT_TIMEOUT) and the queues did not "
+                         "drain within 10 s: its buffers may still be written to";
+    return SSD_E_DEVICE;
+}
+
 static void aql_teardown(ssd_env *env) {
     if (!env->aql) return;
     AqlState &A = *env->aql;
@@ -722,6 +746,13 @@ static bool aql_ready(ssd_env *env, int chains) {
         A.flag_kernarg = ssd::aql::host_kernarg_alloc(env->device, 64);
         if (!A.flag_kernarg) return false;
         std::memcpy(A.flag_kernarg, &A.join_counter, sizeof(void *));
+        {
+            void *h = nullptr, *d = nullptr;
+            if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+            A.timed_out_host = static_cast<uint32_t *>(h); A.timed_out_dev = static_cast<uint32_t *>(d);
+            *A.timed_out_host = 0;
+            env->host_allocs.push_back(h);
+        }
         ptr = nullptr;
         if (hipMalloc(&ptr, 8) != hipSuccess || hipMemset(ptr, 0, 8) != hipSuccess) { (void)hipGetLastError(); return false; }
         A.fork_counter = static_cast<unsigned long long *>(ptr);
@@ -731,7 +762,7 @@ static bool aql_ready(ssd_env *env, int chains) {
             // inside somebody's first short rollout -- and before the pool's first queue is probed (the probe launches one of them)
             ssd::aql::signal_set(A.fork_sig[0], 1);
             ssd::launch_signal_kernel(ssd::aql::signal_value_ptr(A.fork_sig[0]), nullptr);
-            ssd::launch_wait_counter_kernel(A.join_counter, 0, nullptr, 0, nullptr, nullptr);
+            ssd::launch_wait_counter_kernel(A.join_counter, 0, nullptr, 0, nullptr, nullptr, nullptr);
             ssd::launch_flag_kernel(A.fork_counter, nullptr); A.forks = 1;
             if (hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipGetLastError(); return false; }
         }
@@ -945,7 +976,7 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
             // (nothing is in the library's queues yet: an error here leaves nothing behind)
             if (hipGetLastError() != hipSuccess) { A.forks--; env->err = "fork kernel launch failed"; return SSD_E_DEVICE; }
             // (the wait is bounded -- a minute: what the stream holds ahead of the call may be a whole training step)
-            ssd::WaitArgs wa{A.fork_counter, A.forks, ssd::aql::abort_flag_dev(env->device), 6000000000ull, env->p.status};
+            ssd::WaitArgs wa{A.fork_counter, A.forks, ssd::aql::abort_flag_dev(env->device), 6000000000ull, env->p.status, A.timed_out_dev};
             uint8_t *ka = A.fork_kernarg + (size_t)slot * AqlState::kForkBlock;
             std::memcpy(ka, &wa, sizeof wa);
             for (int c = 0; c < chains; ++c) {
@@ -1044,7 +1075,7 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
     if (test_timeout_ms > 0) timeout_ticks = (unsigned long long)test_timeout_ms * 100000ull;
     (void)hipGetLastError();                              // (an earlier, unrelated sticky error of the caller's must not be read as ours)
     ssd::launch_wait_counter_kernel(A.join_counter, A.joins + (test_lost ? 1000000ull : 0ull), ssd::aql::abort_flag_dev(env->device), timeout_ticks,
-                                    env->p.status, s);
+                                    env->p.status, A.timed_out_dev, s);
     if (hipGetLastError() != hipSuccess) {
         // the chains' packets are out and nothing on the stream waits for them: wait here, so that the call's work is over (and
         // its results in place) when the error is returned -- nobody frees or reuses memory under running kernels
@@ -1062,11 +1093,20 @@ static int rollout_aql(ssd_env *env, int chains, const ChainJob *jobs, hipStream
 static int rollout(ssd_env *env, const int32_t *actions, const uint8_t *order, int32_t action_ring, int32_t num_actions, int32_t n_steps,
                    int32_t reset_every, int32_t step0, void *obs, int32_t *rew, uint8_t *done, int32_t ring, uint32_t flags, void *stream) {
     if (obs && (reinterpret_cast<uintptr_t>(obs) & 3u)) { env->err = "obs must be 4-byte aligned"; return SSD_E_INVALID; }
+    // SSD_ROLLOUT_AUTO: the form of the call is the library's choice.  The fused kernel is the fastest form there is (4096 Harvest
+    // envs: 3.5 us per step of a long call against 5.4 through the chains, 4.5 against 6.1 - 6.6 in 20-step calls) wherever it
+    // applies: uint8 observations, index action order, and more than one step (a single step is one launch either way, and the
+    // per-step kernels are the shorter ones).  ssd_rollout_path() reports the form that ran.
+    if (flags & SSD_ROLLOUT_AUTO) {
+        flags &= ~(uint32_t)SSD_ROLLOUT_AUTO;
+        if (!(flags & SSD_OBS_F32) && !order && n_steps >= 2) flags |= SSD_ROLLOUT_FUSED;
+    }
     if ((flags & SSD_ROLLOUT_FUSED) && (flags & SSD_OBS_F32)) { env->err = "the fused rollout kernel writes uint8 observations"; return SSD_E_INVALID; }
     {
         int cur = -1;
         if (hipGetDevice(&cur) != hipSuccess || cur != env->device) SSD_HIP(env, hipSetDevice(env->device));
     }
+    if (const int rc = after_timeout(env)) return rc;               // (an earlier call's join gave up: reported once, here or in ssd_synchronize)
     hipStream_t s = static_cast<hipStream_t>(stream);
     env->last_stream = s; env->last_stream_set = true;
     uint8_t *o = static_cast<uint8_t *>(obs);
@@ -1443,7 +1483,7 @@ int ssd_synchronize(ssd_env *env) {
     if (!env) return SSD_E_INVALID;
     SSD_HIP(env, hipSetDevice(env->device));
     SSD_HIP(env, hipDeviceSynchronize());
-    return SSD_OK;
+    return after_timeout(env);      // (SSD_E_DEVICE once if a rollout call's join wait gave up meanwhile: the queues are drained first)
 }
 
 }  // extern "C"

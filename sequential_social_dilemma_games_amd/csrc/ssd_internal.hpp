@@ -137,10 +137,11 @@ const void *flag_kernel_fn();                          // ssd_flag_kernel's host
 const void *wait_kernel_fn();                          // ssd_wait_counter_kernel's host stub (AQL fork: a chain's first packet)
 void launch_flag_kernel(unsigned long long *counter, void *stream);   // AQL fork: bump a counter from a HIP stream
 // the kernel arguments of ssd_wait_counter_kernel as its kernarg segment lays them out
-struct WaitArgs { const unsigned long long *counter; unsigned long long target; const uint32_t *abort; unsigned long long timeout_ticks; uint32_t *status; };
+struct WaitArgs { const unsigned long long *counter; unsigned long long target; const uint32_t *abort; unsigned long long timeout_ticks; uint32_t *status; uint32_t *timed_out; };
 // the stream-side wait of the AQL join: gives up after `timeout_ticks` of the 100 MHz clock and then sets kStWaitTimeout in *status
+// and 1 in *timed_out (host memory the device can write: the handle's sticky flag, looked at by the next API call)
 void launch_wait_counter_kernel(const unsigned long long *counter, unsigned long long target, const uint32_t *abort,
-                                unsigned long long timeout_ticks, uint32_t *status, void *stream);
+                                unsigned long long timeout_ticks, uint32_t *status, uint32_t *timed_out, void *stream);
 #ifdef SSD_STAMPS
 void launch_clock_kernel(unsigned long long *out, int iters, void *stream);
 #endif

@@ -1846,7 +1846,7 @@ __global__ void ssd_flag_kernel(unsigned long long *counter) {
 // (ssd_capi.hip, sync mode, chosen automatically when a tool is attached); should it still get here, the wave gives up, sets
 // SSD_ST_WAIT_TIMEOUT in the handle's status word -- the call's results are not in place -- and lets the stream go on.
 __global__ void ssd_wait_counter_kernel(const unsigned long long *counter, unsigned long long target, const volatile uint32_t *abort,
-                                        unsigned long long timeout_ticks, uint32_t *status) {
+                                        unsigned long long timeout_ticks, uint32_t *status, uint32_t *timed_out) {
     if (threadIdx.x != 0) return;
     uint32_t spins = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -1856,6 +1856,8 @@ __global__ void ssd_wait_counter_kernel(const unsigned long long *counter, unsig
             if (abort && *abort) break;
             if (timeout_ticks && __builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
                 if (status) atomicOr(status, kStWaitTimeout);
+                // (host memory: the handle's next API call sees it without touching the device -- ssd_capi.hip, after_timeout)
+                if (timed_out) __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
         }
@@ -1887,9 +1889,9 @@ void launch_flag_kernel(unsigned long long *counter, void *stream) {
     hipLaunchKernelGGL(ssd_flag_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), counter);
 }
 void launch_wait_counter_kernel(const unsigned long long *counter, unsigned long long target, const uint32_t *abort,
-                                unsigned long long timeout_ticks, uint32_t *status, void *stream) {
+                                unsigned long long timeout_ticks, uint32_t *status, uint32_t *timed_out, void *stream) {
     hipLaunchKernelGGL(ssd_wait_counter_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), counter, target, abort,
-                       timeout_ticks, status);
+                       timeout_ticks, status, timed_out);
 }
 void launch_signal_kernel(long long *signal_value, void *stream) {
     hipLaunchKernelGGL(ssd_signal_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), signal_value);

@@ -128,13 +128,11 @@ class VecEngine(object):
         self.steps_since_full_reset = 0 if mask is None else None
         return obs
 
-    def step(self, actions, order=None, out=None, auto_reset=False, chains=False):
+    def step(self, actions, order=None, out=None, auto_reset=False):
         """MapEnv.step (map_env.py:152-212) on every env.  actions: i32 [E,N] (-1 = absent);
         order: optional u8 [E,N] action-dict order.  Returns (obs, rew, done) device tensors.
         auto_reset: envs that reach the horizon (set_horizon) are reset by the same launch, their obs rows are the
-        reset's (SSD_AUTO_RESET; uint8 observations only).
-        chains: dispatch the step like a one-step rollout_actions() call (SSD_STEP_CHAINS: env ranges stepped concurrently
-        through the library's own queues); index action order, no auto_reset."""
+        reset's (SSD_AUTO_RESET; uint8 observations only)."""
         torch, dev = self._torch()
         self._check_tensor(actions, (self.E, self.N), torch.int32, "actions")
         if order is not None:
@@ -149,7 +147,7 @@ class VecEngine(object):
             po, pr, pd, fl = self._dp(obs), self._dp(rew), self._dp(done), self._obs_flags(obs)
             self._out_cache = (out, (po, pr, pd, fl))
         rc = self._L.ssd_step(self._h, C.c_void_p(actions.data_ptr()), self._dp(order), po, pr, pd,
-                              fl | (_capi.SSD_AUTO_RESET if auto_reset else 0) | (_capi.SSD_STEP_CHAINS if chains else 0), self._stream())
+                              fl | (_capi.SSD_AUTO_RESET if auto_reset else 0), self._stream())
         if rc:
             _capi.check(rc, self._h)
         self._count_after_step(auto_reset)
@@ -225,11 +223,12 @@ class VecEngine(object):
         dimension R: step k writes slot (step0 + k) % R  (obs u8 or f32 [R,E,N,V,V,3], rew i32 [R,E,N], done u8 [R,E,N]).
         Same launches as n_steps calls of step_random(); the host just stops being the bottleneck.
         fused=True: ONE kernel launch for the whole call (SSD_ROLLOUT_FUSED) -- every env stays in LDS / registers across
-        its steps; same results, uint8 observations only."""
+        its steps; same results, uint8 observations only.  fused="auto": the library picks (SSD_ROLLOUT_AUTO: the fused kernel
+        for uint8 observations and two steps or more, the chains otherwise; rollout_path() says which form ran)."""
         po, pr, pd, ring, f32 = self._rollout_args(obs, rew, done)
         na = self.num_actions if num_actions is None else int(num_actions)
         rc = self._L.ssd_rollout_random(self._h, na, int(n_steps), int(reset_every), int(step0), po, pr, pd, ring,
-                                        f32 | (_capi.SSD_ROLLOUT_FUSED if fused else 0), self._stream())
+                                        f32 | self._fused_flag(fused), self._stream())
         if rc:
             _capi.check(rc, self._h)
         self._count_rollout(n_steps, reset_every, step0)
@@ -239,7 +238,8 @@ class VecEngine(object):
         actions) per step (visuallizer_rllib.py:121-153), for a recorded sequence / an action chunk of n_steps steps.
         actions: int32 [A,E,N] device tensor (-1 = the agent does not act); step k reads slot (step0 + k) % A.  order: optional
         uint8 [A,E,N], per step the agent indices in action-dict order, 0xFF-terminated (None: index order).  Outputs as
-        rollout_random().  Reuse the same action / output tensors from call to call: the launches' arguments are cached by them."""
+        rollout_random() (fused=True / "auto" as there).  Reuse the same action / output tensors from call to call: the launches'
+        arguments are cached by them."""
         torch, dev = self._torch()
         cache = getattr(self, "_act_cache", None)
         if cache is not None and cache[0] is actions and cache[1] is order:
@@ -253,19 +253,29 @@ class VecEngine(object):
             self._act_cache = (actions, order, (pa, pord, aring))
         po, pr, pd, ring, f32 = self._rollout_args(obs, rew, done)
         rc = self._L.ssd_rollout_actions(self._h, pa, pord, aring, int(n_steps), int(reset_every), int(step0), po, pr, pd, ring,
-                                         f32 | (_capi.SSD_ROLLOUT_FUSED if fused else 0), self._stream())
+                                         f32 | self._fused_flag(fused), self._stream())
         if rc:
             _capi.check(rc, self._h)
         self._count_rollout(n_steps, reset_every, step0)
 
+    @staticmethod
+    def _fused_flag(fused):
+        if isinstance(fused, str):
+            if fused != "auto":
+                raise ValueError("fused must be True, False or 'auto'")
+            return _capi.SSD_ROLLOUT_AUTO
+        return _capi.SSD_ROLLOUT_FUSED if fused else 0
+
     def rollout_path(self):
         """How the last rollout call was dispatched (ssd_rollout_path): {"aql", "coherent", "split", "fused", "sync", "forked",
-        "queue_dropped": bool, "chains": n, "pool": dispatch queues the device's pool settled on} -- lets a benchmark or a test
+        "queue_dropped": bool, "chains": n, "pool": dispatch queues the device's pool settled on, "agent_match": how the HSA agent
+        of the handle's HIP device was found ("pci" / "uuid" / "ordinal" / "none")} -- lets a benchmark or a test
         tell a silent fallback from the path it meant to measure."""
         m = self._L.ssd_rollout_path(self._h)
         return {"aql": bool(m & _capi.SSD_PATH_AQL), "coherent": bool(m & _capi.SSD_PATH_COHERENT), "split": bool(m & _capi.SSD_PATH_SPLIT),
                 "fused": bool(m & _capi.SSD_PATH_FUSED), "sync": bool(m & _capi.SSD_PATH_SYNC), "forked": bool(m & _capi.SSD_PATH_FORKED),
-                "queue_dropped": bool(m & _capi.SSD_PATH_QUEUE_DROPPED), "chains": (m >> 8) & 15, "pool": (m >> 12) & 7}
+                "queue_dropped": bool(m & _capi.SSD_PATH_QUEUE_DROPPED), "chains": (m >> 8) & 15, "pool": (m >> 12) & 7,
+                "agent_match": ("none", "pci", "uuid", "ordinal")[(m >> 16) & 3]}
 
     def observe(self, rotate=True, obs=None):
         torch, dev = self._torch()

@@ -294,13 +294,20 @@ class MapEnv(MultiAgentEnv):
         # when the reference indexes its dict cell by cell)
         glyphs = np.asarray(map, dtype='<U1')
         codes = np.ascontiguousarray(glyphs).view(np.uint32).reshape(glyphs.shape)
+        # (an empty cell of a '<U1' array is code point 0 and reads back as '': the reference's DEFAULT_COLOURS has that key,
+        # map_env.py:26; keys that are not one character -- '' aside -- can never equal a cell and are skipped)
+        def glyph_of(code):
+            return chr(int(code)) if code else ''
         for code in np.unique(codes):
-            if chr(int(code)) not in color_map:
-                raise KeyError(chr(int(code)))
+            if glyph_of(code) not in color_map:
+                raise KeyError(glyph_of(code))
         table = np.zeros((int(codes.max()) + 1 if codes.size else 1, 3), dtype=int)
         for glyph, rgb in color_map.items():
-            if ord(glyph) < table.shape[0]:
-                table[ord(glyph)] = rgb
+            if not isinstance(glyph, str) or len(glyph) > 1:
+                continue
+            code = ord(glyph) if glyph else 0
+            if code < table.shape[0]:
+                table[code] = rgb
         return table[codes]
 
     def render(self, filename=None):

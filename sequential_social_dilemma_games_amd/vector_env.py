@@ -70,11 +70,12 @@ class SSDVectorEnv(object):
             return
         self.engine.reset(mask=done[:, 0].contiguous(), obs=obs)
 
-    def step(self, actions):
-        """actions: int32 [E,N] on the device.  Returns (obs u8, rew i32, done u8) device tensors; envs whose
-        episode just ended have been reset and their obs rows replaced by the new episode's first observation."""
+    def step(self, actions, order=None):
+        """actions: int32 [E,N] on the device (-1: the agent sent no action); order: optional uint8 [E,N] on the device, per env
+        the agent indices in action-dict order, 0xFF-terminated (None: index order).  Returns (obs u8, rew i32, done u8) device
+        tensors; envs whose episode just ended have been reset and their obs rows replaced by the new episode's first observation."""
         in_kernel = self._in_kernel()
-        obs, rew, done = self.engine.step(actions, out=self._out, auto_reset=in_kernel)
+        obs, rew, done = self.engine.step(actions, order=order, out=self._out, auto_reset=in_kernel)
         self._auto_reset(obs, done, in_kernel)
         # (rows of envs whose episode just ended carry a reset's observation: their other_agent_actions are the reset's zeros)
         return self._wrap(obs, actions, done if self.horizon > 0 else None), rew, done
@@ -130,13 +131,30 @@ class SSDVectorEnv(object):
         return o, r, d, i, {}
 
     def send_actions(self, action_dict):
+        """{env_id: {agent_id: action}}.  The reference's step depends on the iteration order of the inner dicts (who is
+        shuffled where in update_moves, whose beam lands first: map_env.py:171,379,546), so the order of every env's dict goes to
+        the kernel with the actions, as MapEnv.step passes its own (map_env.py of this package); envs whose dicts are in
+        index order -- what RLlib's sampler sends -- need none, and a batch of only such envs takes the map-specific kernels."""
         import torch
-        act = np.full((self.num_envs, self.num_agents), K.NO_ACTION, np.int32)
+        N = self.num_agents
+        act = np.full((self.num_envs, N), K.NO_ACTION, np.int32)
+        order = np.full((self.num_envs, N), 0xFF, np.uint8)
+        index_of = {a: k for k, a in enumerate(self.agent_ids)}
+        explicit = False
         for e, per_agent in action_dict.items():
-            for a, v in per_agent.items():
-                act[e, self.agent_ids.index(a)] = int(v)
+            last = -1
+            for k, (a, v) in enumerate(per_agent.items()):
+                i = index_of[a]                                  # KeyError for an unknown agent, as in the reference
+                act[e, i] = int(v)
+                order[e, k] = i
+                explicit = explicit or i < last
+                last = i
         dev = torch.device("cuda", self.engine.device)
-        self._pending = self.step(torch.from_numpy(act).to(dev))
+        if explicit:
+            # (envs that sent nothing keep an empty order: nobody acts there, which is what their all -1 action rows say too)
+            self._pending = self.step(torch.from_numpy(act).to(dev), torch.from_numpy(order).to(dev))
+        else:
+            self._pending = self.step(torch.from_numpy(act).to(dev))
 
     def try_reset(self, env_id):
         import torch

@@ -29,6 +29,19 @@ def test_gpus_2_starts_two_ranks_with_contiguous_shards():
     assert res["gpu_max_hw_queues"] == "2"
 
 
+def test_gpus_8_dry_run_is_eight_ranks_eight_shards_one_line():
+    """The shape of the driver's scaling run (N = 8: one rank per GPU, weak scaling, shards (r * E, E)) on the CPU: eight gloo
+    ranks under torch.distributed.run, the legs that need no GPU included, ONE line from rank 0."""
+    p = _run(["--gpus", "8", "--dry-run", "--dry-run-legs", "--envs", "4096"])
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["ranks"] == 8
+    assert res["shards"] == [[r * 4096, 4096] for r in range(8)]
+    assert res["gpu_max_hw_queues"] == "2" and res["cpu_baseline"]["value"] > 0
+
+
 def test_single_rank_needs_no_launcher():
     p = _run(["--gpus", "1", "--dry-run", "--envs", "100"])
     assert p.returncode == 0, p.stderr.decode()[-2000:]

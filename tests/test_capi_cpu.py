@@ -65,7 +65,7 @@ def test_python_constants_match_the_header():
         expr = m.group(1).strip().replace("u", "")
         return int(eval(expr))                                   # "1 << 3", "-2", ...
 
-    for name in ("SSD_HOST_PTRS", "SSD_NO_ROTATE", "SSD_OBS_F32", "SSD_ROLLOUT_FUSED", "SSD_AUTO_RESET", "SSD_STEP_CHAINS"):
+    for name in ("SSD_HOST_PTRS", "SSD_NO_ROTATE", "SSD_OBS_F32", "SSD_ROLLOUT_FUSED", "SSD_AUTO_RESET", "SSD_ROLLOUT_AUTO"):
         assert getattr(_capi, name) == value(name), name
     for name in ("SSD_ST_BAD_ACTION", "SSD_ST_NO_SPAWN", "SSD_ST_MOVE_LOOKUP", "SSD_ST_WAIT_TIMEOUT"):
         assert getattr(_capi, name) == value(name), name

@@ -188,3 +188,47 @@ def test_vector_env_batches_the_observation_dict():
         assert bool((obs["visible_agents"] == 1).all())
     o, r, d, i, _ = vec.poll()
     assert o[0]["agent-3"]["other_agent_actions"].dtype == np.int64
+
+
+@pytest.mark.gpu
+def test_vector_env_dict_surface_honours_the_action_dicts_order():
+    """VERDICT r03 missing #3: the reference's step depends on the iteration order of the `actions` dict (map_env.py:171,379,546).
+    The recorded rollout x2 (random subsets of the agents in random dict orders, one reset mid-way) is replayed FREE-RUNNING
+    through SSDVectorEnv.poll / send_actions / try_reset with the recorded dicts -- the recorded env among others that are sent
+    the same actions in INDEX order, so the batch mixes orders -- against the fixture's observations, rewards and
+    other_agent_actions.  (Index-order semantics for a permuted dict would diverge at the first contested move.)"""
+    from sequential_social_dilemma_games_amd.vector_env import SSDVectorEnv, _NORMALISE
+    g = xload("x2_harvest_16x38_n5_raa_subsets")
+    s, r, N = g.steps, g.resets, g.N
+    E, j = 4, 2
+    assert int(g.env) >= j
+    vec = SSDVectorEnv(g.game, E, N, horizon=0, ascii_map=g.map, seed=g.seed, env_index_base=int(g.env) - j, return_agent_actions=True)
+    ids = vec.agent_ids
+    o, _, d, _, _ = vec.poll()                                     # the first poll resets (episode 0)
+    for i, a in enumerate(ids):
+        np.testing.assert_array_equal(o[j][a]["curr_obs"], _NORMALISE[r["obs"][0][i]])
+        np.testing.assert_array_equal(o[j][a]["other_agent_actions"], r["oaa"][0][i])
+    permuted = 0
+    for k in range(g.n_steps):
+        if k and s["episode"][k] != s["episode"][k - 1]:           # the reference was reset here (gen_golden_extras.py)
+            first = vec.try_reset(j)
+            for i, a in enumerate(ids):
+                np.testing.assert_array_equal(first[a]["curr_obs"], _NORMALISE[r["obs"][1][i]], err_msg="reset before step %d" % k)
+        order = [int(x) for x in s["order"][k] if x != 255]
+        permuted += order != sorted(order)
+        recorded = {ids[i]: int(s["act"][k, i]) for i in order}    # the recorded dict, in the recorded order
+        in_index_order = {ids[i]: int(s["act"][k, i]) for i in sorted(order)}
+        vec.send_actions({e: (recorded if e == j else in_index_order) for e in range(E)})
+        o, rw, d, _, _ = vec.poll()
+        for i, a in enumerate(ids):
+            np.testing.assert_array_equal(o[j][a]["curr_obs"], _NORMALISE[s["obs"][k][i]], err_msg="observation of %s, step %d" % (a, k))
+            assert rw[j][a] == int(s["rew"][k][i]), "reward of %s, step %d" % (a, k)
+            np.testing.assert_array_equal(o[j][a]["other_agent_actions"], s["oaa"][k][i][:int(s["oaa_len"][k][i])], err_msg="step %d" % k)
+            np.testing.assert_array_equal(o[j][a]["visible_agents"], s["vis"][k][i])
+        assert not d[j]["__all__"]
+    assert permuted >= 5, "the fixture is supposed to hold permuted dicts"
+    st = vec.engine.get_state()
+    np.testing.assert_array_equal(st["world"][j], s["world"][-1])
+    np.testing.assert_array_equal(st["pos"][j], s["pos"][-1])
+    assert vec.engine.status() == 0
+    vec.engine.close()

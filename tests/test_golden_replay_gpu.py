@@ -59,16 +59,16 @@ def test_reference_rollouts_replayed_free_running(name, mode):
     obs = torch.zeros((R, E, N, 15, 15, 3), dtype=torch.uint8, device="cuda")
     rew = torch.zeros((R, E, N), dtype=torch.int32, device="cuda")
     done = torch.ones((R, E, N), dtype=torch.uint8, device="cuda")
-    k, call, seen = 0, 0, set()
+    # (what is compared first is the DATA, call by call; how every call was dispatched is collected and asserted at the end, so
+    # that a box on which the library's own queues are not available -- SSD_AQL=0, an unmatched HSA agent, a queue that fails its
+    # probe -- still checks the parity of ssd_rollout_actions against the reference and reports the dispatch mismatch separately)
+    k, call, seen, paths = 0, 0, set(), []
     while k < n:
         m = min(CHUNKS[call % len(CHUNKS)], n - k)
         eng.rollout_actions(acts, m, obs, rew, done, reset_every=k_reset, step0=k, fused=(mode == "fused"), order=order)
         path = eng.rollout_path()
-        if mode == "fused":
-            assert path["fused"] and not path["aql"], path
-        else:
-            assert path["aql"] and path["chains"] == 2, path
-            seen.add((path["coherent"], path["split"]))
+        paths.append(path)
+        seen.add((path["coherent"], path["split"]))
         torch.cuda.synchronize()
         got_obs = obs[:, j].cpu().numpy()
         got_rew = rew[:, j].cpu().numpy()
@@ -84,6 +84,13 @@ def test_reference_rollouts_replayed_free_running(name, mode):
         k += m
         call += 1
     assert not done[:min(n, R)].any().item() and eng.status() == 0     # (slots no step wrote keep their initial 1)
+    # ... and only now the dispatch path (every comparison above has passed: the data is right whatever path ran)
+    for path in paths:
+        if mode == "fused":
+            assert path["fused"] and not path["aql"], "data matched the reference, but the call was not dispatched as the fused kernel: %r" % (path,)
+        else:
+            assert path["aql"] and path["chains"] == 2, ("data matched the reference, but the call did not go through the library's own "
+                                                         "queues as 2 chains (SSD_AQL=0? agent match / queue probe fell back?): %r" % (path,))
     if mode == "chains":
         fast = order is None and N in (5, 10) and os.environ.get("SSD_AQL_COHERENT", "1") != "0"
         if fast:      # the map-specific kernels: coherent chains, split from 4 steps on -- both forms were exercised

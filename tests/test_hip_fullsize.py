@@ -126,12 +126,23 @@ def test_join_wait_is_bounded():
         "st = eng.status()\n"
         "print('status', st, 'seconds', round(time.time() - t0, 3))\n"
         "assert st & _capi.SSD_ST_WAIT_TIMEOUT, st\n"
-        "assert time.time() - t0 < 5.0\n" % root)
+        "assert time.time() - t0 < 5.0\n"
+        # the timeout is STICKY: the next rollout call drains the library's queues on the host, reports the\n"
+        # condition once and takes the handle off that path; the call after it steps through hipLaunchKernel\n"
+        "try:\n"
+        "    eng.rollout_random(2, obs, None, None, reset_every=0, step0=6)\n"
+        "    raise SystemExit('the call after a timed-out join did not report it')\n"
+        "except _capi.SsdError as e:\n"
+        "    assert 'timed out' in str(e), str(e)\n"
+        "eng.rollout_random(2, obs, None, None, reset_every=0, step0=6)\n"
+        "torch.cuda.synchronize()\n"
+        "assert not eng.rollout_path()['aql'], eng.rollout_path()\n"
+        "print('sticky ok')\n" % root)
     env = dict(os.environ, SSD_AQL_TEST_LOST_JOIN="1", SSD_AQL_TEST_TIMEOUT_MS="50", SSD_LIB_PATH=HOOKS_LIB)
     env.pop("SSD_AQL_SYNC", None)
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = r.stdout.decode(errors="replace")
-    assert r.returncode == 0 and "status" in out, out[-2000:]
+    assert r.returncode == 0 and "status" in out and "sticky ok" in out, out[-2000:]
 
 
 def test_sync_mode_gives_the_same_results():

@@ -576,9 +576,9 @@ def test_rollout_actions_matches_the_oracle(game, mode):
     o_obs, o_rew, _ = ora.step(np.full((E, N), -1, np.int32))
     o_obs, o_rew, _ = ora.step(np.full((E, N), -1, np.int32))
     np.testing.assert_array_equal(obs[(total + 1) % ring].cpu().numpy(), o_obs)
-    # afterwards the ordinary paths continue from the same state; a plain step through the chains (SSD_STEP_CHAINS) too
+    # afterwards the ordinary paths continue from the same state
     a1 = rng.randint(0, na, size=(E, N)).astype(np.int32)
-    o2, r2, _ = eng.step(torch.from_numpy(a1).cuda(), chains=True)
+    o2, r2, _ = eng.step(torch.from_numpy(a1).cuda())
     o_obs, o_rew, _ = ora.step(a1)
     np.testing.assert_array_equal(o2.cpu().numpy(), o_obs)
     np.testing.assert_array_equal(r2.cpu().numpy(), o_rew)
