@@ -131,12 +131,25 @@ __device__ __forceinline__ void unit_vec(int code, int &dr, int &dc) {
     dc = code == 2 ? -1 : (code == 3 ? 1 : 0);
 }
 
+// Vector memory accesses with a cache policy go through the buffer instructions' builtins -- buffer_load / buffer_store with
+// sc1 (agent scope: past the CU's L1 and not left dirty in the XCD's L2), nt (non-temporal: past the memory-side cache) or both in
+// the instruction's cache-policy field -- NOT through inline asm: the compiler tracks these loads (its own s_waitcnt vmcnt before
+// the first use, wherever that is, also under divergent control flow) and the hazards around the stores.  Round 3 had them as
+// `asm volatile("global_load_dwordx4 ... sc1")`, which the compiler believes complete when the statement ends: one wrong grid and
+// one memory fault came of it.  A buffer resource names a wave-uniform byte range; an access beyond it is dropped (stores) or
+// returns zero (loads), which is also the bounds check of the lanes past a grid's end.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int kAuxSc1 = 16, kAuxNt = 2, kAuxSc1Nt = 18;           // cache-policy bits of the gfx94x / gfx950 buffer builtins
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, uint32_t bytes) {
+    // (wave-uniform by construction -- an env's or an agent's block -- and said so: the descriptor lives in four SGPRs)
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+}
 // Observation stores are write-through (sc1 = agent scope: the data leaves for HBM as it is produced).  With ordinary
 // stores the 13.8 MB of a 4096-env step sit dirty in L2 until the end-of-kernel write-back, which the next launch has to
-// wait for: 8.0 -> 6.9 us per step.  `base` is wave-uniform (SGPR pair), `off` the lane's byte offset; any alignment.
-// The s_nops are the gfx9 hazards the compiler cannot see through inline asm: a VMEM instruction must not read an SGPR
-// that a VALU instruction (v_readfirstlane) wrote less than 5 wait states earlier, and a VMEM store of more than 64 bits
-// reads its data registers late, so a VALU write to one of them needs wait states after the store.
+// wait for: 8.0 -> 6.9 us per step.  `r` names the env's observation block, `soff` (wave-uniform) the agent's offset in it,
+// `off` the lane's byte offset; any alignment.
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -157,18 +170,22 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // as hoped -- env waves 15 % shorter, stores land in 950 cycles instead of 2 700 -- but a piece's 16 bytes are 5 1/3 view cells of
 // up to two agents, so cell coordinates become per-lane arithmetic where the 12-byte form has per-lane CONSTANTS: the renderer's
 // render phase grows from 3 100 to 5 400 cycles and the renderer wave becomes the launch's critical path: 7.6 against 7.03 us.
-__device__ __forceinline__ void store12_wt(uint8_t *base, uint32_t off, u32x3_t d, int wt) {
+__device__ __forceinline__ void store12_wt(rsrc_t r, uint32_t soff, uint32_t off, u32x3_t d, int wt) {
     // (the usual policy first: in the fused kernel's step loop every test in front of it showed, 3.75 -> 3.91 us per step)
-    if (wt == 1) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
-    else if (wt == 3) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 nt\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
-    else if (wt == 2) asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 sc1 nt\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
-    else asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+    if (wt == 1) __builtin_amdgcn_raw_buffer_store_b96(d, r, (int)off, (int)soff, kAuxSc1);
+    else if (wt == 3) __builtin_amdgcn_raw_buffer_store_b96(d, r, (int)off, (int)soff, kAuxNt);
+    else if (wt == 2) __builtin_amdgcn_raw_buffer_store_b96(d, r, (int)off, (int)soff, kAuxSc1Nt);
+    else __builtin_amdgcn_raw_buffer_store_b96(d, r, (int)off, (int)soff, 0);
 }
-__device__ __forceinline__ void store16_wt(float *base, uint32_t off, f32x4_t d, int wt) {
-    if (wt >= 2) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1 nt\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
-    else if (wt) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
-    else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(d), "s"(base) : "memory");
+__device__ __forceinline__ void store16_wt(rsrc_t r, uint32_t soff, uint32_t off, f32x4_t f, int wt) {
+    const u32x4_t d = __builtin_bit_cast(u32x4_t, f);
+    if (wt >= 2) __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)off, (int)soff, kAuxSc1Nt);
+    else if (wt) __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)off, (int)soff, kAuxSc1);
+    else __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)off, (int)soff, 0);
 }
+// 16 bytes with one agent-scope load / store
+__device__ __forceinline__ u32x4_t load16_sc1(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, kAuxSc1); }
+__device__ __forceinline__ void store16_sc1(rsrc_t r, uint32_t off, u32x4_t d) { __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)off, 0, kAuxSc1); }
 
 // bytes of x that are non-zero -> 0xFF, others 0x00
 __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
@@ -200,6 +217,7 @@ __device__ __forceinline__ void render_views_std(const int lane, const int WP, c
     }
     uint32_t off3 = (uint32_t)pp0 * 3u;                                 // byte offset of the lane's cells in an agent's block
     asm volatile("" : "+v"(off3));                                      // keep it in a register (else re-derived per agent)
+    const rsrc_t out_r = make_rsrc(out_env, (uint32_t)NA * SSD_OBS_STRIDE);
     for (int ag0 = 0; ag0 < NA; ag0 += kB) {
         uint32_t addr[kB][4], px[kB][4];
 #pragma unroll
@@ -242,7 +260,7 @@ __device__ __forceinline__ void render_views_std(const int lane, const int WP, c
             // policy behind each other (a test per store showed in the fused kernel's step loop: 3.75 -> 3.91 us per step).
             auto stores = [&](auto policy) {
 #pragma unroll
-                for (int u = 0; u < kB; ++u) store12_wt(out_env + (size_t)(ag0 + u) * SSD_OBS_STRIDE, off3, d[u], decltype(policy)::value);
+                for (int u = 0; u < kB; ++u) store12_wt(out_r, (uint32_t)(ag0 + u) * SSD_OBS_STRIDE, off3, d[u], decltype(policy)::value);
             };
             if (wt == 1) stores(std::integral_constant<int, 1>{});
             else if (wt == 3) stores(std::integral_constant<int, 3>{});
@@ -408,14 +426,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 // sc0 loads (L2, past L1 only in threadgroup-split mode) returned stale lines in the env waves)
                 constexpr int kGridLoads = (fm.S + 1023) / 1024;       // the grid in pieces of 1 KiB, all fetched at once
                 u32x4_t g0[kGridLoads];
-                const uint8_t *gsrc = a_world + (size_t)eb * S;
+                // (lanes past the grid's end address beyond the buffer: they get zeros and store nothing)
+                const rsrc_t grid_r = make_rsrc(a_world + (size_t)eb * S, (uint32_t)S);
 #pragma unroll
-                // (every lane loads, lanes past the grid's end the last 16 bytes again: an asm load under a divergent branch would
-                // leave the compiler free to copy its -- not yet written -- destination register when the branches join)
-                for (int j = 0; j < kGridLoads; ++j) {
-                    const int off = lane * 16 + j * 1024;
-                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g0[j]) : "v"(gsrc + (off < S ? off : S - 16)) : "memory");
-                }
+                for (int j = 0; j < kGridLoads; ++j) g0[j] = load16_sc1(grid_r, (uint32_t)(lane * 16 + j * 1024));
                 uint32_t areg = 0;
                 if (lane < N) areg = __hip_atomic_load(a_agents + (size_t)eb * N + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // (what the step left beside its state: bits 20 / 21 of agent 0's word -- a list of beam marks / an overlay
@@ -427,9 +441,6 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     for (int i = lane; i < n0 + n1; i += 64)
                         *reinterpret_cast<uint4 *>(i < n0 ? s_world - A0 + i * 16 : s_world + S + (i - n0) * 16) = z;
                 }
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0[0]) : : "memory");
-#pragma unroll
-                for (int j = 1; j < kGridLoads; ++j) asm volatile("" : "+v"(g0[j]));      // (not to be read before the wait)
                 s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b;
                 const uint32_t flags = rfl(areg) >> 20;
                 const bool snapshot = (flags & 2u) != 0, marks = (flags & 1u) != 0;
@@ -438,15 +449,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 constexpr bool kTwoLists = GAME == 1 && NA > 5;        // (as kTwoPasses of the env role below)
                 if (kTwoLists && (flags & 4u)) entry2 = __hip_atomic_load(p.beam_list_in + ((size_t)p.E_total + eb) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (snapshot) {                                         // (rare: the overlay as the step left it, instead of the state)
-                    gsrc = p.snap_in + (size_t)eb * S;
+                    const rsrc_t snap_r = make_rsrc(p.snap_in + (size_t)eb * S, (uint32_t)S);
 #pragma unroll
-                    for (int j = 0; j < kGridLoads; ++j) {
-                        const int off = lane * 16 + j * 1024;
-                        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g0[j]) : "v"(gsrc + (off < S ? off : S - 16)) : "memory");
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0[0]) : : "memory");
-#pragma unroll
-                    for (int j = 1; j < kGridLoads; ++j) asm volatile("" : "+v"(g0[j]));
+                    for (int j = 0; j < kGridLoads; ++j) g0[j] = load16_sc1(snap_r, (uint32_t)(lane * 16 + j * 1024));
                 }
 #pragma unroll
                 for (int j = 0; j < kGridLoads; ++j)
@@ -511,13 +516,6 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         auto cload = [](const uint32_t *ptr) -> uint32_t {
             return kCoh ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ptr;
         };
-        // 16 bytes with one agent-scope load.  (Inline asm: the compiler does not know the load is outstanding -- every use is
-        // behind the explicit s_waitcnt vmcnt(0) below; its own vmcnt waits only become more conservative by foreign entries.)
-        auto cload16 = [](const uint8_t *ptr) -> u32x4_t {
-            u32x4_t v;
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory");
-            return v;
-        };
         // (coherent variants: lanes 0..3 fetch the header's four words.  The v_readlanes right behind the load make the wave
         // wait for it before it issues the others -- two round trips to memory in a row.  Measured, not reasoned: reading the
         // lanes out after the common wait shortens the wave by 0.2 us (diagnostic build: load phase 1605 -> 1138 cycles) and
@@ -566,18 +564,16 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // to memory on the wave's path: 25 x 38 Harvest 2 pieces, 48 x 36 Cleanup 3)
         constexpr int kGridLoads = FAST ? (fm.S + 1023) / 1024 : 1;
         uint4 w0[kGridLoads], b0 = make_uint4(0, 0, 0, 0);
-        u32x4_t w0c[kGridLoads];                                        // (coherent variants: the asm loads' destinations)
+        // (coherent variants: agent-scope buffer loads; lanes past the grid's end address beyond the buffer and get zeros)
+        const rsrc_t grid_r = make_rsrc(gsrc, (uint32_t)S);              // (unused, and dropped, in the other variants)
         auto issue_grid = [&]() {
 #pragma unroll
             for (int j = 0; j < kGridLoads; ++j) {
                 w0[j] = make_uint4(0, 0, 0, 0);
-                w0c[j] = u32x4_t{0u, 0u, 0u, 0u};
                 const int off = lane * 16 + j * 1024;
-                if (kCoh) {
-                    // (every lane loads, lanes past the grid's end the last 16 bytes again: an asm load under a divergent branch
-                    // would leave the compiler free to copy its -- not yet written -- destination when the branches join;
-                    // only lanes inside the grid store what they loaded)
-                    w0c[j] = cload16(gsrc + (off < S ? off : S - 16));
+                if constexpr (kCoh) {
+                    const u32x4_t v = load16_sc1(grid_r, (uint32_t)off);
+                    w0[j] = make_uint4(v.x, v.y, v.z, v.w);
                 } else if (off < S) {
                     w0[j] = *reinterpret_cast<const uint4 *>(gsrc + off);
                 }
@@ -628,14 +624,6 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             ti = ti < p.n_thr ? ti : p.n_thr - 1;
             thr_pa = p.thr_ca[ti]; thr_pw = p.thr_cw[ti];
         }
-        if (kCoh) {                                                      // (the asm loads above)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0c[0]) : : "memory");
-#pragma unroll
-            for (int j = 0; j < kGridLoads; ++j) {
-                if (j) asm volatile("" : "+v"(w0c[j]));                  // (not to be read before the wait)
-                w0[j] = make_uint4(w0c[j].x, w0c[j].y, w0c[j].z, w0c[j].w);
-            }
-        }
         uint32_t key = rfl(hdr.x), t = rfl(hdr.y), episode = rfl(hdr.z);
         if (a_obs) { s_lut[lane] = lut_a; s_lut[lane + 64] = lut_b; }
         if (obs_f32) { reinterpret_cast<float4 *>(s_f32)[lane] = flut; reinterpret_cast<float4 *>(s_f32)[lane + 64] = flut_b; }
@@ -659,9 +647,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         for (int i = lane * 16 + 1024 * kGridLoads; i < S; i += 1024) {   // (general kernel) maps above 1024 cells
             uint4 bv = make_uint4(0, 0, 0, 0);
             if (mode == kModeObserve && keep_beams) bv = *reinterpret_cast<const uint4 *>(p.beam + (size_t)e * S + i);
-            if (kCoh) {
-                u32x4_t wv = cload16(gsrc + i);
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wv) : : "memory");
+            if constexpr (kCoh) {
+                const u32x4_t wv = load16_sc1(grid_r, (uint32_t)i);
                 *reinterpret_cast<uint4 *>(s_world + i) = make_uint4(wv.x, wv.y, wv.z, wv.w);
             } else {
                 *reinterpret_cast<uint4 *>(s_world + i) = *reinterpret_cast<const uint4 *>(gsrc + i);
@@ -691,6 +678,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 // (render_flags, split rollouts: what the renderer will find beside this state -- bits 20 / 21 of agent 0's
                 // word: a list of beam marks / an overlay snapshot; readers of the word take bits 0..17)
                 auto cstore = [](uint32_t *ptr, uint32_t v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+                const rsrc_t out_r = make_rsrc(gw, (uint32_t)S);         // (16-byte write-through stores; past the grid's end: dropped)
                 if constexpr (FAST != 0 && SSD_WB_UNROLL) {
                     // a known map's grid is kGridLoads pieces of 1 KiB: all of them are read out of LDS first, into registers of their
                     // own, and the stores then follow each other -- as a loop (LDS read, wait, store, next piece into the same
@@ -705,14 +693,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     for (int j = 0; j < kGridLoads; ++j) {
                         const int off = lane * 16 + j * 1024;
                         const u32x4_t v = {v4[j].x, v4[j].y, v4[j].z, v4[j].w};
-                        if (off < S) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(gw + off), "v"(v) : "memory");
+                        store16_sc1(out_r, (uint32_t)off, v);
                     }
                 } else
                 for (int i = lane * 16; i < S; i += 64 * 16) {
                     const uint4 v4 = *reinterpret_cast<const uint4 *>(s_world + i);
                     const u32x4_t v = {v4.x, v4.y, v4.z, v4.w};
-                    // one 16-byte write-through store (the s_nop: a store of more than 64 bits reads its data registers late)
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(gw + i), "v"(v) : "memory");
+                    store16_sc1(out_r, (uint32_t)i, v);                 // one 16-byte write-through store
                 }
                 if (is_agent) cstore(ga + (size_t)e * N + lane, cell | (orient << 16) | (lane == 0 ? render_flags : 0u));
                 if (lane < 4) cstore(reinterpret_cast<uint32_t *>(a_hdr + e) + lane,
@@ -1482,11 +1469,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             wave_sync();
             if constexpr (stepping && COH) {
                 if ((p.snap_mode & 1) && is_step && !patch) {                 // (the rare form: the overlay as a snapshot)
-                    uint8_t *sg = p.snap + (size_t)e * S;
+                    const rsrc_t snap_r = make_rsrc(p.snap + (size_t)e * S, (uint32_t)S);
                     for (int i = lane * 16; i < S; i += 64 * 16) {
                         const uint4 v4 = *reinterpret_cast<const uint4 *>(s_view + i);
-                        const u32x4_t v = {v4.x, v4.y, v4.z, v4.w};
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(sg + i), "v"(v) : "memory");
+                        store16_sc1(snap_r, (uint32_t)i, u32x4_t{v4.x, v4.y, v4.z, v4.w});
                     }
                 }
             }
@@ -1535,6 +1521,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     // run past the block's end starts four floats before the end instead (same values, written twice).
                     const int nf = VV * 3, n_st = (nf + 255) >> 8;
                     float *base_env = reinterpret_cast<float *>(a_obs) + (slot_en + (size_t)e * N) * (size_t)nf;
+                    const rsrc_t f32_r = make_rsrc(base_env, (uint32_t)(N * nf * 4));
                     for (int k4 = 0; k4 < n_st; ++k4) {
                         const int f_raw = k4 * 256 + 4 * lane;
                         const bool on = f_raw < nf;
@@ -1565,13 +1552,16 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                             o.y = r0 ? t[0].y : r1 ? t[0].z : t[1].x;
                             o.z = r0 ? t[0].z : r1 ? t[1].x : t[1].y;
                             o.w = r0 ? t[1].x : r1 ? t[1].y : t[1].z;
-                            if (on) store16_wt(base_env + (size_t)ag * nf, (uint32_t)f0 * 4u, o, p.obs_wt);
+                            if (on) store16_wt(f32_r, (uint32_t)(ag * nf * 4), (uint32_t)f0 * 4u, o, p.obs_wt);
                         }
                     }
                 } else if constexpr (STD && NA > 0 && NA % 5 == 0 && !F32) {
                     // Specialised kernels: five agents per pass (render_views_std)
                     render_views_std<NA>(lane, WP, a_k, a_s0, world_lds, s_lut, out_env, p.obs_wt);
-                } else
+                } else {
+                // (the env's observation block as a buffer: uint8 [N][V][V][3], or the same cells as float32)
+                const rsrc_t gen_r = obs_f32 ? make_rsrc(reinterpret_cast<float *>(a_obs) + (slot_en + (size_t)e * N) * VV * 3, (uint32_t)(N * VV * 12))
+                                             : make_rsrc(out_env, (uint32_t)(N * VV * 3));
                 for (int base = 0; base < VV; base += 256) {
                     // A lane renders 4 consecutive cells = one 12-byte store.  V*V is not a multiple of 4 (225 = 56*4 + 1):
                     // the lane holding the leftover cells starts 4 cells before the end instead, re-rendering up to 3
@@ -1624,11 +1614,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                             }
                             if (VV >= 4) {
                                 if (lane_on) {
-                                    float *basef = reinterpret_cast<float *>(a_obs) + ((slot_en + (size_t)e * N + ag) * VV) * 3;   // wave-uniform
 #pragma unroll
                                     for (int k4 = 0; k4 < 3; ++k4) {
                                         f32x4_t v4 = {f[4 * k4], f[4 * k4 + 1], f[4 * k4 + 2], f[4 * k4 + 3]};
-                                        store16_wt(basef, (uint32_t)pp0 * 12u + 16u * k4, v4, p.obs_wt);
+                                        store16_wt(gen_r, (uint32_t)(ag * VV * 12), (uint32_t)pp0 * 12u + 16u * k4, v4, p.obs_wt);
                                     }
                                 }
                             } else {
@@ -1649,7 +1638,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                                 d.x = __builtin_amdgcn_perm(px[1], px[0], 0x04020100u);   // r0 g0 b0 r1
                                 d.y = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);   // g1 b1 r2 g2
                                 d.z = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);   // b2 r3 g3 b3
-                                store12_wt(out_env + (size_t)ag * VV * 3, off3, d, p.obs_wt);
+                                store12_wt(gen_r, (uint32_t)(ag * VV * 3), off3, d, p.obs_wt);
                             }
                         } else {
 #pragma unroll
@@ -1661,6 +1650,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                                 }
                         }
                     }
+                }
                 }
             }
             if (auto_mode) {                                  // (done = t >= horizon: the env's next episode starts in this launch)

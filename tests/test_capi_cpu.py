@@ -118,11 +118,10 @@ def test_profiler_detection(var, want):
     assert int(r.stdout.decode().strip().splitlines()[-1]) == want
 
 
-def test_inflight_asm_loads_are_not_touched_before_their_wait():
-    """The coherent kernels fetch an env's grid with inline-asm agent-scope loads the compiler cannot see as outstanding.  Nothing
-    may read or write their destination registers before the s_waitcnt that covers them (tools/check_asm_loads.py on the ISA of the
-    committed sources; round 3 lost a grid piece to a load under a divergent branch, and a kernel to asm loads with much code
-    between issue and wait)."""
+def test_no_vector_memory_instruction_is_inline_asm():
+    """the coherent kernels' agent-scope / non-temporal loads and stores are the compiler-tracked buffer builtins,
+    not inline asm the compiler cannot see as outstanding (round 3 lost a grid piece to such a load under a divergent branch, and
+    a kernel to asm loads with much code between issue and wait).  tools/check_no_asm_vmem.py on the committed source and its ISA."""
     import shutil
     import subprocess
     import sys
@@ -131,6 +130,7 @@ def test_inflight_asm_loads_are_not_touched_before_their_wait():
     csrc = os.path.join(REPO, "sequential_social_dilemma_games_amd", "csrc")
     r = subprocess.run(["make", "-C", csrc, "ARCH=gfx950", "asm"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_asm_loads.py"), os.path.join(csrc, "ssd_kernels.s")],
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_no_asm_vmem.py"), os.path.join(csrc, "ssd_kernels.hip"),
+                        os.path.join(csrc, "ssd_kernels.s")],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert r.returncode == 0, r.stdout.decode()[-3000:]

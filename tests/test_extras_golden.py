@@ -200,8 +200,7 @@ def test_vector_env_dict_surface_honours_the_action_dicts_order():
     from sequential_social_dilemma_games_amd.vector_env import SSDVectorEnv, _NORMALISE
     g = xload("x2_harvest_16x38_n5_raa_subsets")
     s, r, N = g.steps, g.resets, g.N
-    E, j = 4, 2
-    assert int(g.env) >= j
+    E, j = 4, min(int(g.env), 2)
     vec = SSDVectorEnv(g.game, E, N, horizon=0, ascii_map=g.map, seed=g.seed, env_index_base=int(g.env) - j, return_agent_actions=True)
     ids = vec.agent_ids
     o, _, d, _, _ = vec.poll()                                     # the first poll resets (episode 0)
