@@ -316,7 +316,8 @@ def test_the_bench_configuration_takes_the_native_dispatch_path():
     out = eng.alloc_outputs()
     ring = tuple(t.unsqueeze(0) for t in out)
     eng.set_rollout_chains(2)
-    assert not any(v for v in eng.rollout_path().values())           # before the first rollout call: nothing
+    first = eng.rollout_path()                                       # before the first rollout call: nothing
+    assert not any(v for k, v in first.items() if k != "agent_match") and first["agent_match"] == "none", first
     eng.rollout_random(20, *ring, reset_every=1000)
     torch.cuda.synchronize()
     path = eng.rollout_path()
@@ -326,6 +327,8 @@ def test_the_bench_configuration_takes_the_native_dispatch_path():
     core = {k: path[k] for k in ("aql", "coherent", "split", "fused", "sync", "chains")}
     assert core == {"aql": want_aql, "coherent": want_coh, "split": want_split, "fused": False, "sync": False, "chains": 2}, path
     assert not path["queue_dropped"] and (path["pool"] >= 2 or not want_aql), path   # (a plain process: the pool's two queues pass their probe)
+    # (the HSA agent of the HIP device is found by its PCI address -- the fallbacks, UUID and ordinal, are for boxes that hide it)
+    assert path["agent_match"] == ("pci" if want_aql else "none"), path
     # the path must not be named before it is certain -- more argument blocks than the library keeps go through
     # hipLaunchKernel, and ssd_rollout_path says so
     big_rew = torch.empty((1100,) + tuple(ring[1].shape[1:]), dtype=torch.int32, device="cuda")
