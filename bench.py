@@ -53,7 +53,7 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s achievable
 XGMI_LINK_GBS = 153.0        # per direct peer link (7 per GPU)
 HORIZON = 1000               # run_scripts/train_baseline.py:131
-ROUND = "r03"
+ROUND = "r04"
 
 
 def _oracle_worker(game, amap, n_agents, E, seconds, seed, out, idx):
@@ -573,11 +573,11 @@ def main():
                          "host_enqueue_us_per_step": enq * 1e6 / args.steps},
         }
         # HBM bytes per step from the PMC counters of the committed profile of this exact workload
-        # (tools/profile_r03.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE correction)
+        # (tools/profile_workloads.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE correction)
 
         def traffic():
             tkey = "%s_%dx%d_n%d_e%d%s" % (args.game.rstrip("0123456789x"), eng.H, eng.W, n_agents, E, "_f32" if args.obs_f32 else "")
-            for rnd in (ROUND, "r02", "r01"):
+            for rnd in (ROUND, "r03", "r02", "r01"):
                 tpath = os.path.join(REPO, "profiles", "%s_traffic.json" % rnd)
                 if not os.path.exists(tpath):
                     continue
@@ -679,6 +679,24 @@ def main():
                 finally:
                     eng.set_rollout_chains(args.chains)
             run_leg(holder, "fused_rollout", fused)
+
+            # ---- optional leg, labelled: the same K steps with SSD_ROLLOUT_AUTO -- the library picks the form of the call (uint8
+            #      observations, index action order, two steps or more: the fused kernel) and says which it picked.  Not `value`. ----
+            def auto_leg():
+                eng.set_rollout_chains(0)
+                try:
+                    aw, _, _ = time_rollout(torch, eng, ring, args.steps, args.warmup, fused="auto")
+                    path = eng.rollout_path()
+                    aus = aw * 1e6 / args.steps
+                    if eng.status() != 0:
+                        raise RuntimeError("device status word is non-zero")
+                    return {"label": "NOT the headline: the same %d steps with SSD_ROLLOUT_AUTO (the library chooses the form of the call; "
+                                     "`dispatch` says which form ran)" % args.steps,
+                            "us_per_step": aus, "value": float(E) * n_agents * args.steps / aw, "unit": "agent-env-steps/s per GPU",
+                            "roofline_frac": bytes_env * E / (aus * 1e-6) / 1e9 / HBM_PEAK_GBS, "dispatch": path}
+                finally:
+                    eng.set_rollout_chains(args.chains)
+            run_leg(holder, "rollout_auto", auto_leg)
         # ---- optional legs WITH collectives (opt-in): north_star: "RCCL gather of obs/reward over xGMI only when a single batched
         #      tensor is requested".  The same rollout in chunks of GR steps, each chunk's observations and rewards (a) all-gathered to
         #      every rank, (b) gathered to rank 0 (the root ingests its 7 peers' shards over 7 direct links), one

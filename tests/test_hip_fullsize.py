@@ -344,6 +344,49 @@ def test_the_bench_configuration_takes_the_native_dispatch_path():
     assert eng.status() == 0
 
 
+@pytest.mark.parametrize("game_name", ["harvest", "cleanup"])
+def test_rollout_auto_lets_the_library_choose_the_form(game_name):
+    """SSD_ROLLOUT_AUTO (task 3c): with uint8 observations, index action order and two steps or more the call runs as
+    the fused kernel, anything else as without the flag -- ssd_rollout_path says which -- and the results are the oracle's either
+    way (device-drawn and caller-supplied actions; a one-step call; float32 observations; an explicit action order)."""
+    import torch
+    game, amap = (K.GAME_HARVEST, K.HARVEST_MAP) if game_name == "harvest" else (K.GAME_CLEANUP, K.CLEANUP_MAP)
+    E, N, na = 2304, 5, (8 if game_name == "harvest" else 9)
+    _rollout_vs_oracle(game, amap, E, N, seed=9, steps=17, step0=2, every=11, ring=3, chains=0, fused="auto")
+    _rollout_vs_oracle(game, amap, E, N, seed=10, steps=9, step0=0, every=0, ring=2, chains=0, actions=True, fused="auto")
+    eng = VecEngine(game, amap, num_envs=E, num_agents=N, seed=11)
+    ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), seed=11)
+    obs = torch.zeros((1, E, N, 15, 15, 3), dtype=torch.uint8, device="cuda")
+    rew = torch.zeros((1, E, N), dtype=torch.int32, device="cuda")
+    eng.reset()
+    ora.reset()
+    eng.rollout_random(6, obs, rew, None, fused="auto")
+    assert eng.rollout_path()["fused"], eng.rollout_path()
+    for _ in range(6):
+        _, o_obs, o_rew, _ = ora.step_random()
+    assert np.array_equal(obs[0].cpu().numpy(), o_obs) and np.array_equal(rew[0].cpu().numpy(), o_rew)
+    eng.rollout_random(1, obs, rew, None, step0=6, fused="auto")             # one step: one launch either way, the per-step kernel
+    assert not eng.rollout_path()["fused"], eng.rollout_path()
+    _, o_obs, o_rew, _ = ora.step_random()
+    assert np.array_equal(obs[0].cpu().numpy(), o_obs) and np.array_equal(rew[0].cpu().numpy(), o_rew)
+    obs_f = torch.zeros((1, E, N, 15, 15, 3), dtype=torch.float32, device="cuda")
+    eng.rollout_random(4, obs_f, rew, None, step0=7, fused="auto")           # float32 observations: the fused kernel writes none
+    assert not eng.rollout_path()["fused"], eng.rollout_path()
+    for _ in range(4):
+        _, o_obs, o_rew, _ = ora.step_random()
+    np.testing.assert_array_equal(obs_f[0].cpu().numpy(), ((o_obs.astype(np.float64) - 128.0) / 255.0).astype(np.float32))
+    rng = np.random.RandomState(3)                                           # an explicit action order: the general kernels, per step
+    a_host = rng.randint(0, na, size=(3, E, N)).astype(np.int32)
+    order = np.stack([np.stack([rng.permutation(N) for _ in range(E)]) for _ in range(3)]).astype(np.uint8)
+    eng.rollout_actions(torch.from_numpy(a_host).cuda(), 3, obs, rew, None, step0=0, fused="auto", order=torch.from_numpy(order).cuda())
+    assert not eng.rollout_path()["fused"], eng.rollout_path()
+    for k in range(3):
+        o_obs, o_rew, _ = ora.step(a_host[k], order=order[k])
+    assert np.array_equal(obs[0].cpu().numpy(), o_obs) and np.array_equal(rew[0].cpu().numpy(), o_rew)
+    assert eng.status() == 0
+    eng.close()
+
+
 @pytest.mark.parametrize("hwq,chains", [(None, 2), ("1", 3), ("2", 2), ("3", 1)])
 def test_automatic_chains_stay_within_the_queue_budget(hwq, chains):
     """A process has about four hardware queues before the device time-slices them; the HIP runtime takes up to GPU_MAX_HW_QUEUES of

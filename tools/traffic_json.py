@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/<round>_traffic.json (python tools/traffic_json.py r03) from the rocprofv3 summaries tools/profile_<round>.sh leaves in gpurun_out/<round>_prof/<tag>/:
+"""profiles/<round>_traffic.json (python tools/traffic_json.py r04) from the rocprofv3 summaries tools/profile_workloads.sh <round> leaves in gpurun_out/<round>_prof/<tag>/:
 HBM bytes per step = (2 x FETCH_SIZE + WRITE_SIZE) KiB of the step kernel's dispatches (separate --pmc passes; FETCH_SIZE doubled per
 the gfx950 correction of MI355X_MICROARCH.md) x the launches of one step, next to the algorithmic bytes of SURVEY.md 8d; plus
 the step kernel's average duration under --kernel-trace.  Also copies the per-workload summaries into profiles/."""
@@ -14,7 +14,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from sequential_social_dilemma_games_amd import config as cfgmod  # noqa: E402
 
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC = os.path.join(REPO, "gpurun_out", "%s_prof" % ROUND)
 DST = os.path.join(REPO, "profiles")
 WORK = {   # tag -> (H, W, N, E, chains, f32)
@@ -64,7 +64,7 @@ def main():
                 ent.update(fetch_size_kib_per_launch=f, write_size_kib_per_launch=w,
                            hbm_bytes_per_launch=int(round((2 * f + w) * 1024 * chains)), algorithmic_bytes_per_step=alg * E)
                 ent["ratio"] = round(ent["hbm_bytes_per_launch"] / ent["algorithmic_bytes_per_step"], 3)
-                ent["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_%s.sh; host-side waits, chosen by the "
+                ent["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_workloads.sh %s; host-side waits, chosen by the "
                                "library itself under a tool); FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM).  bench.py steps the "
                                "envs as %d concurrent launch(es) per step; the counters are per launch, hbm_bytes_per_launch here is the sum over the "
                                "launches of one step." % (ROUND, chains))
