@@ -702,9 +702,9 @@ static int after_timeout(ssd_env *env) {
     }
     __atomic_store_n(A.timed_out_host, 0u, __ATOMIC_RELEASE);
     A.ok = false;
-    env->err = drained ? "a rollout call's wait for the library's dispatch queues timed out (SSD_ST_WAIT_TIMEOUT): its outputs may be incomplete; "
+    env->err = drained ? "a rollout call's wait for the library's dispatch queues timed out (the WAIT_TIMEOUT status bit): its outputs may be incomplete; "
                          "the queues have been drained and the handle now steps through hipLaunchKernel"
-                       : "a rollout call's wait for the library's dispatch queues timed out (SSD_ST_WAIT_TIMEOUT) and the queues did not "
+                       : "a rollout call's wait for the library's dispatch queues timed out (the WAIT_TIMEOUT status bit) and the queues did not "
                          "drain within 10 s: its buffers may still be written to";
     return SSD_E_DEVICE;
 }
