@@ -72,6 +72,9 @@ __device__ __forceinline__ uint32_t env_key(uint32_t seed_lo, uint32_t seed_hi, 
 __device__ __forceinline__ uint32_t phase_key(uint32_t key, uint32_t t, uint32_t stream) {
     return mix32(mix32(key ^ t) ^ stream);
 }
+// (the two halves of phase_key: the first is the same for every stream of a step -- computed once per pass, on the scalar unit)
+__device__ __forceinline__ uint32_t step_key(uint32_t key, uint32_t t) { return mix32(key ^ t); }
+__device__ __forceinline__ uint32_t stream_key(uint32_t skey, uint32_t stream) { return mix32(skey ^ stream); }
 __device__ __forceinline__ uint32_t draw(uint32_t pkey, uint32_t index) { return mix32(pkey ^ index); }
 __device__ __forceinline__ uint32_t randint(uint32_t u, uint32_t n) { return __umulhi(u, n); }
 
@@ -461,13 +464,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 if (!snapshot) {
                     // get_map_with_agents (map_env.py:280-302): agents in index order -- the highest index on a cell shows --
                     // then the beams over them
-                    const uint64_t agents_m = N >= 64 ? ~0ull : bit((uint32_t)N) - 1;
-                    uint64_t highest = 0;
-                    for (int j = 0; j < N; ++j) {
-                        const uint64_t here = ballot(cellb == rl(cellb, j)) & agents_m;
-                        highest |= ((here >> j) >> 1) ? 0ull : bit(j);
-                    }
-                    if (__builtin_amdgcn_inverse_ballot_w64(highest & agents_m)) s_world[cellb] = agent_glyph((uint32_t)lane);
+                    // (which agents those are the step's wave has said in bit 19 of their words: it had compared the cells anyway)
+                    if (lane < N && (areg & (1u << 19))) s_world[cellb] = agent_glyph((uint32_t)lane);
                     wave_sync();
                     if (marks) {
                         if (entry) s_world[entry & 0xFFFFu] = (uint8_t)(entry >> 16);
@@ -479,7 +477,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     }
                 }
                 SSD_BSTAMP(1, __builtin_readcyclecounter());                // layer ready
-                const uint32_t kq = orientb == 2 ? 0u : orientb == 0 ? 1u : orientb == 3 ? 2u : 3u;     // rotate_view: UP 0, LEFT 1, DOWN 2, RIGHT 3
+                const uint32_t kq = (0x8Du >> (2u * orientb)) & 3u;     // rotate_view: UP 0, LEFT 1, DOWN 2, RIGHT 3 (a 2-bit table by orientation code; as a chain of selects it compiled to exec-mask branches)
                 const uint32_t s0 = (uint32_t)((int)cellb - 7 * (WP + 1) + (kq >= 2 ? 14 * (WP + 1) : 0));
                 render_views_std<NA>(lane, WP, kq, s0, (uint32_t)(uintptr_t)(lds_u8 *)s_world, s_lut, p.obs_b + (size_t)eb * N * SSD_OBS_STRIDE, p.obs_wt);
                 SSD_BSTAMP(2, __builtin_readcyclecounter());                // stores issued
@@ -557,7 +555,12 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         uint32_t areg = 0;
         int act_in = -1;
         uint32_t ord_in = 0xFFu;
-        if (mode != kModeReset && is_agent) areg = cload(a_agents + (size_t)e * N + lane);
+        // (the env's offset in every [E][N] array -- agents, actions, rewards, dones -- computed ONCE and kept in a scalar register: left
+        // to the compiler it is re-derived inside every predicated block that uses it, a 64-bit multiply each)
+        uint32_t eN32 = rfl((uint32_t)e * (uint32_t)N);
+        asm volatile("" : "+s"(eN32));
+        const size_t eN = eN32;
+        if (mode != kModeReset && is_agent) areg = cload(a_agents + eN + lane);
         const uint8_t *gsrc = mode == kModeReset ? p.reset_world : a_world + (size_t)e * S;
         // (a known map's grid is kGridLoads pieces of 1 KiB, 16 bytes per lane each: ALL of them go out here -- fetched one after
         // the other behind the first, as the general kernel's loop below does, every piece past the first is another round trip
@@ -606,8 +609,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         if (stepping && is_agent) {
             // (caller-supplied actions: a coherent launch reads them past the caches too -- between a chain's launches nothing
             // invalidates a CU's L1, and the same action buffer may have held another call's actions a moment ago)
-            if (p.num_actions_random <= 0) act_in = (int)cload(reinterpret_cast<const uint32_t *>(p.actions) + (size_t)e * N + lane);
-            if (has_order) ord_in = p.order[(size_t)e * N + lane];
+            if (p.num_actions_random <= 0) act_in = (int)cload(reinterpret_cast<const uint32_t *>(p.actions) + eN + lane);
+            if (has_order) ord_in = p.order[eN + lane];
         }
 #pragma unroll
         for (int j = 0; j < kLR; ++j) {
@@ -669,7 +672,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // and only the 16-byte pieces the spawn pass changed written again at the end: Harvest 4096 envs 5.50 against 5.50 us per
         // step (a first pair of runs said 5.43 against 5.54: box noise), 2048 envs 4.68 against 4.61, 8192 envs 10.56 against
         // 10.37, Cleanup 25 x 18 5.96 against 5.87, 48 x 36 8.14 against 7.73: the stores are not what the wave's end waits for)
-        auto write_state = [&](const uint32_t render_flags) {
+        // (`top_bit`, per lane: bit 19 of the agent's word = "the highest index on its cell" -- what shows on the cell,
+        // map_env.py:289-297 -- for the renderer workgroups of the next launch: they then need not compare the agents' cells pair by
+        // pair again)
+        auto write_state = [&](const uint32_t render_flags, const uint32_t top_bit = 0u) {
             uint8_t *gw = a_world + (size_t)e * S;
             if constexpr (kCoh) {
                 // (split rollouts: grid and agents go to the other buffer of the pair, this launch's renderer waves read the input)
@@ -701,9 +707,15 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     const u32x4_t v = {v4.x, v4.y, v4.z, v4.w};
                     store16_sc1(out_r, (uint32_t)i, v);                 // one 16-byte write-through store
                 }
-                if (is_agent) cstore(ga + (size_t)e * N + lane, cell | (orient << 16) | (lane == 0 ? render_flags : 0u));
-                if (lane < 4) cstore(reinterpret_cast<uint32_t *>(a_hdr + e) + lane,
-                                     lane == 0 ? key : lane == 1 ? t : lane == 2 ? episode : (waste_last | (waste_cur << 16)));
+                if (is_agent) cstore(ga + eN + lane, cell | (orient << 16) | top_bit | (lane == 0 ? render_flags : 0u));
+                {   // the header's four words, one per lane: three v_writelane into a register that holds the fourth everywhere (as a
+                    // chain of selects on the lane index the compiler made ~20 instructions of nested exec-mask branches of it)
+                    uint32_t hw = waste_last | (waste_cur << 16);
+                    asm("v_writelane_b32 %0, %1, 0" : "+v"(hw) : "s"(key));
+                    asm("v_writelane_b32 %0, %1, 1" : "+v"(hw) : "s"(t));
+                    asm("v_writelane_b32 %0, %1, 2" : "+v"(hw) : "s"(episode));
+                    if (lane < 4) cstore(reinterpret_cast<uint32_t *>(a_hdr + e) + lane, hw);
+                }
                 if (status && lane == 0) atomicOr(p.status, status);
                 return;
             }
@@ -712,7 +724,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 if (keep_beams)
                     *reinterpret_cast<uint4 *>(p.beam + (size_t)e * S + i) = *reinterpret_cast<const uint4 *>(s_beam + i);
             }
-            if (is_agent) a_agents[(size_t)e * N + lane] = cell | (orient << 16);
+            if (is_agent) a_agents[eN + lane] = cell | (orient << 16);
             if (lane == 0) a_hdr[e] = make_uint4(key, t, episode, waste_last | (waste_cur << 16));
             if (status && lane == 0) atomicOr(p.status, status);
         };
@@ -796,8 +808,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             uint32_t ordv = (uint32_t)lane;                      // action order list, lane k = k-th acting agent
             int nord = N;
             bool all_apart = false;                              // known: no two agents share a cell after the moves
+            if (is_step) t += 1;
+            // (every keyed draw of this pass -- actions, move shuffle, apples, waste coins and order -- hashes (key, t) first: once,
+            // here, instead of once per stream inside whatever branch needs one: 12 scalar instructions per further stream)
+            const uint32_t skey = step_key(key, t);
             if (is_step) {
-                t += 1;
                 // ---- actions (map_env.py:171-173) ----
                 constexpr int kNumActions = GAME == 0 ? 8 : 9;   // harvest.py:44, cleanup.py:70
                 if constexpr (roll_acts) {                       // (fused rollout, caller-supplied actions: fetched a pass ago)
@@ -806,10 +821,10 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     const bool bad = is_agent && (act < -1 || act >= kNumActions);
                     if (ballot(bad)) { status |= kStBadAction; if (bad) act = -1; }
                 } else if (roll || p.num_actions_random > 0) {   // rollout.py:64-65 uniform random actions
-                    const uint32_t pk = phase_key(key, t, kAction);
+                    const uint32_t pk = stream_key(skey, kAction);
                     if (is_agent) {
                         act = (int)randint(draw(pk, (uint32_t)lane), (uint32_t)p.num_actions_random);
-                        if (!roll && p.actions_out) p.actions_out[(size_t)e * N + lane] = act;
+                        if (!roll && p.actions_out) p.actions_out[eN + lane] = act;
                     }
                 } else {                                         // (drawn actions are valid by construction: ssd_step_random checks n)
                     act = act_in;
@@ -890,7 +905,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                                 if ((M >> a) & 1) { if (lane == cnt) perm = a; ++cnt; }
                             }
                         }
-                        const uint32_t pk = phase_key(key, t, kMove);
+                        const uint32_t pk = stream_key(skey, kMove);
                         // draw i is keyed by i alone: lane i computes its own, all at once; only the swaps are sequential
                         const uint32_t jv = randint(draw(pk, (uint32_t)lane), (uint32_t)lane + 1);
                         for (int i = nm - 1; i >= 1; --i) {      // :421-423 np.random.shuffle = Fisher-Yates from the end
@@ -1240,7 +1255,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 // The LDS reads of one list entry are unconditional (padding entries point at an interior
                 // cell), so they go out as one independent batch.
                 uint64_t spawn_bits = 0;                                                // bit j: list entry lane + 64*j gets an apple
-                const uint32_t pk_apple = phase_key(key, t, kApple);
+                const uint32_t pk_apple = stream_key(skey, kApple);
                 const int a_iters = (n_apple + 63) >> 6;
                 const uint32_t safe = (uint32_t)(WP + 1);                               // cell (1,1)
                 uint32_t waste_cell = 0xFFFFFFFFu;
@@ -1255,6 +1270,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     const uint32_t t0 = p.thr_h32[0], d1 = p.thr_h32[1] - t0, d2 = p.thr_h32[2] - p.thr_h32[1],
                                    d3 = p.thr_h32[3] - p.thr_h32[2];
                     // 3x3 apple count, threshold and keyed draw of one candidate cell (:90-103)
+                    // (measured and dropped, round 4: the three cells of a row as ONE unaligned 4-byte LDS read and the apples among them by
+                    // byte arithmetic -- 3 reads + 13 vector instructions instead of 8 + ~30; the compiler emits ds_read_b32 for it, and
+                    // the hardware serves it slowly: 5.14 -> 5.35 us per 4096-env step, the fused kernel 3.39 -> 3.86)
                     auto wins = [&](uint32_t ce) -> bool {
                         const int c = (int)(ce & 0xFFFFu);
                         uint32_t n = 0;
@@ -1356,7 +1374,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     if (thr_w) {
                         // :144-153 shuffled scan, first non-'H' point whose coin succeeds (at most one per step):
                         // order = ascending (ORDER draw, cell), coin keyed by cell.
-                        const uint32_t pk_coin = phase_key(key, t, kWasteCoin), pk_ord = phase_key(key, t, kWasteOrder);
+                        const uint32_t pk_coin = stream_key(skey, kWasteCoin), pk_ord = stream_key(skey, kWasteOrder);
                         bool has = false;
                         uint32_t bh = 0, bl = 0;
                         auto waste = [&](uint32_t ce, bool valid) {
@@ -1403,17 +1421,17 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                                 if (!keep_beams && beams_in_regs && ballot(b_cov0)) render_flags |= 1u << 22;   // (a second list: the later pass's marks)
                         }
                     }
-                    write_state(render_flags);
+                    write_state(render_flags, __builtin_amdgcn_inverse_ballot_w64(highest) ? 1u << 19 : 0u);
                 }
                 if (is_agent && is_step) {
                     // compute_reward (:208); get_done -> False (:209); with a horizon set, the episode ends after `horizon` steps
                     const uint8_t dn = (p.horizon > 0 && t >= (uint32_t)p.horizon) ? 1 : 0;
                     if constexpr (COH) {                                                // (write-through: nothing stays dirty in L2)
-                        if (p.rew) __hip_atomic_store(p.rew + slot_en + (size_t)e * N + lane, rew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (p.done) __hip_atomic_store(p.done + slot_en + (size_t)e * N + lane, dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (p.rew) __hip_atomic_store(p.rew + slot_en + eN + lane, rew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (p.done) __hip_atomic_store(p.done + slot_en + eN + lane, dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     } else {
-                        if (p.rew) p.rew[slot_en + (size_t)e * N + lane] = rew;
-                        if (p.done) p.done[slot_en + (size_t)e * N + lane] = dn;
+                        if (p.rew) p.rew[slot_en + eN + lane] = rew;
+                        if (p.done) p.done[slot_en + eN + lane] = dn;
                     }
                 }
                 wave_sync();
@@ -1507,7 +1525,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 //   address = base + lin0 | base + lin1 | base + C - lin0 | base + C - lin1,   base = cell - v*(WP+1).
                 uint32_t a_s0 = 0, a_k = 0;
                 if (is_agent) {
-                    a_k = (is_step || (!roll && !auto_mode && p.rotate)) ? (orient == 2 ? 0u : orient == 0 ? 1u : orient == 3 ? 2u : 3u) : 0u;
+                    a_k = (is_step || (!roll && !auto_mode && p.rotate)) ? ((0x8Du >> (2u * orient)) & 3u) : 0u;
                     a_s0 = (uint32_t)((int)cell - v * (WP + 1) + (a_k >= 2 ? (V - 1) * (WP + 1) : 0));
                 }
                 const uint32_t world_lds = (uint32_t)(uintptr_t)(lds_u8 *)s_view;       // LDS byte address of grid cell 0
