@@ -489,6 +489,19 @@ int ssd_create(const ssd_config *cfg, ssd_env **out) {
         if ((rc = upload(env, &df, f32lut))) return bail(rc);
         p.f32lut = df;
     }
+    if (cfg->view_len == 7) {   // the per-lane window offsets of the 15 x 15 view (ssd_kernels.hip, render_views_std): constants of the row stride
+        std::vector<uint32_t> vt(64 * 8);
+        for (int l = 0; l < 64; ++l) {
+            const int pp0 = 4 * l > 221 ? 221 : 4 * l;
+            for (int q = 0; q < 4; ++q) {
+                const int pp = pp0 + q, i = pp / 15, j = pp % 15;
+                vt[l * 8 + q] = (uint32_t)(i * WP + j);
+                vt[l * 8 + 4 + q] = (uint32_t)(j * WP + (14 - i));
+            }
+        }
+        if ((rc = upload(env, &d32, vt))) return bail(rc);
+        p.view_tab = d32;
+    }
     if ((rc = upload(env, &d64, thr_ca))) return bail(rc);
     p.thr_ca = d64;
     if ((rc = upload(env, &d64, thr_cw))) return bail(rc);

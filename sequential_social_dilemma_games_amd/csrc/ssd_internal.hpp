@@ -70,6 +70,8 @@ struct Params {
     const uint32_t *waste_cells;   // [n_waste] 'H' or 'R' cells (cleanup.py:59-60), row-major
     const uint32_t *lut;           // [128]   r | g << 8 | b << 16
     const float *f32lut;           // [128][4] glyph -> float32((channel - 128.0) / 255.0) of r, g, b (exact, host-built), 0
+    const uint32_t *view_tab;      // [64][8] (view_len 7 only, else null): lane l's window offsets of its four view cells pp = min(4 l, 221) + q,
+                                   // (i, j) = (pp / 15, pp % 15): L0[q] = i * WP + j, then L1[q] = j * WP + (14 - i) (render_views_std)
     const uint64_t *thr_ca;        // [n_thr] Cleanup apple thresholds by #'H'
     const uint64_t *thr_cw;        // [n_thr] Cleanup waste thresholds by #'H'
     uint32_t thr_h32[4];           // Harvest apple thresholds by min(#neighbour apples, 3): rand < p  <=>  u32 draw < thr

@@ -201,15 +201,24 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
 // all colour-table reads, then the stores: two LDS round trips per pass.  `a_k` / `a_s0` hold, in lane = agent, the agent's
 // quarter turns and the LDS offset of its window's first (k < 2) or last (k >= 2) cell; `view_lds` is the LDS byte address of grid
 // cell 0 of the layer the views show.  (agent.py:76-78 -> utility_funcs.py:59-114, map_env.py:316-339, :669-689.)
-template <int NA>
+// `tab` (the renderer workgroups of split rollouts): the lane's eight window offsets, L0[q] = i*WP + j and L1[q] = j*WP + (14 - i) of
+// its four view cells (i, j) -- per-lane CONSTANTS of the map's row stride -- fetched from a table the host built (Params::view_tab,
+// two 16-byte loads beside the grid's) instead of being computed by every wave of every launch: ~24 vector instructions of a
+// renderer wave's 134.
+template <int NA, bool TAB = false>
 __device__ __forceinline__ void render_views_std(const int lane, const int WP, const uint32_t a_k, const uint32_t a_s0, const uint32_t view_lds,
-                                                 const uint32_t *s_lut, uint8_t *out_env, const int wt) {
+                                                 const uint32_t *s_lut, uint8_t *out_env, const int wt, const uint4 tab0 = uint4{0, 0, 0, 0},
+                                                 const uint4 tab1 = uint4{0, 0, 0, 0}) {
     typedef __attribute__((address_space(3))) const uint8_t lds_u8;
     constexpr int V = 15, VV = 225, kB = 5;
     const int pp_raw = 4 * lane;
     const bool lane_on = pp_raw < VV;
     const int pp0 = pp_raw > VV - 4 ? VV - 4 : pp_raw;                  // lanes past the end repeat the last one
     int L0[4], L1[4];
+    if constexpr (TAB) {
+        L0[0] = (int)tab0.x; L0[1] = (int)tab0.y; L0[2] = (int)tab0.z; L0[3] = (int)tab0.w;
+        L1[0] = (int)tab1.x; L1[1] = (int)tab1.y; L1[2] = (int)tab1.z; L1[3] = (int)tab1.w;
+    } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int pp = pp0 + q;
@@ -217,6 +226,7 @@ __device__ __forceinline__ void render_views_std(const int lane, const int WP, c
         // 24-bit multiply-adds (full rate; a plain `*` becomes a quarter-rate 32-bit multiply here)
         asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(L0[q]) : "v"(i), "s"(WP), "v"(j));
         asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(L1[q]) : "v"(j), "s"(WP), "v"(V - 1 - i));
+    }
     }
     uint32_t off3 = (uint32_t)pp0 * 3u;                                 // byte offset of the lane's cells in an agent's block
     asm volatile("" : "+v"(off3));                                      // keep it in a register (else re-derived per agent)
@@ -424,6 +434,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             if (eb < a_E) {
                 typedef __attribute__((address_space(3))) const uint8_t lds_u8;
                 const uint32_t lut_a = a_lut[lane], lut_b = a_lut[lane + 64];
+                // (the lane's window offsets: constants of the map, render_views_std)
+                const uint4 vt0 = reinterpret_cast<const uint4 *>(p.view_tab)[2 * lane], vt1 = reinterpret_cast<const uint4 *>(p.view_tab)[2 * lane + 1];
                 // (the state was written through this very XCD's L2 a launch ago -- env and renderer workgroup numbers agree modulo
                 // 8 -- but reading it there needs the CU's L1 out of the way: a buffer_inv sc1 per wave makes the step 33 us;
                 // sc0 loads (L2, past L1 only in threadgroup-split mode) returned stale lines in the env waves)
@@ -479,7 +491,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 SSD_BSTAMP(1, __builtin_readcyclecounter());                // layer ready
                 const uint32_t kq = (0x8Du >> (2u * orientb)) & 3u;     // rotate_view: UP 0, LEFT 1, DOWN 2, RIGHT 3 (a 2-bit table by orientation code; as a chain of selects it compiled to exec-mask branches)
                 const uint32_t s0 = (uint32_t)((int)cellb - 7 * (WP + 1) + (kq >= 2 ? 14 * (WP + 1) : 0));
-                render_views_std<NA>(lane, WP, kq, s0, (uint32_t)(uintptr_t)(lds_u8 *)s_world, s_lut, p.obs_b + (size_t)eb * N * SSD_OBS_STRIDE, p.obs_wt);
+                render_views_std<NA, true>(lane, WP, kq, s0, (uint32_t)(uintptr_t)(lds_u8 *)s_world, s_lut, p.obs_b + (size_t)eb * N * SSD_OBS_STRIDE, p.obs_wt,
+                                           vt0, vt1);
                 SSD_BSTAMP(2, __builtin_readcyclecounter());                // stores issued
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 SSD_BSTAMP(3, __builtin_readcyclecounter());                // stores landed
