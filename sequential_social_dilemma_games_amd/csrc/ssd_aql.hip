@@ -568,6 +568,11 @@ bool queue_failed(const Queue *Q) { return Q->error.load() != 0; }
 // has completed"; waiting until fewer than size - 2 packets are outstanding keeps a slot's previous occupant finished.
 static inline void *next_slot(Queue *Q) {
     const uint64_t idx = Q->widx;
+    // (no doorbell ever covers packets on both sides of the ring buffer's end: under rocprofv3 --kernel-trace the runtime's intercept
+    // queue hands the tool the new packets as one range and the tool read past the end of the buffer -- SIGSEGV at the buffer's
+    // page-aligned end inside hsa_signal_store on the doorbell, round 4, whenever a batch of the every-fourth-step doorbells happened
+    // to straddle the wrap; one doorbell more per trip round the ring)
+    if ((idx & Q->mask) == 0 && Q->rung != idx) ring(Q);
     if (idx - g_api.hsa_queue_load_read_index_scacquire(Q->q) >= (uint64_t)Q->mask - 1) {
         ring(Q);                                        // (the consumer must see what we have written before we wait for it)
         while (idx - g_api.hsa_queue_load_read_index_scacquire(Q->q) >= (uint64_t)Q->mask - 1 && !Q->error.load())

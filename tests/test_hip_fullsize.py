@@ -158,6 +158,20 @@ def test_sync_mode_gives_the_same_results():
     assert r.returncode == 0 and "soak ok" in out, out[-2000:]
 
 
+def test_dispatch_queue_ring_wraps_many_times():
+    """The library's dispatch queues are ring buffers it writes itself (ssd_aql.hip): with the test hook SSD_AQL_QUEUE_SIZE=64 a
+    600-step rollout of 2 chains goes round each ring ~20 times -- packets, the every-fourth-step doorbells (never across the ring's
+    end: next_slot), the wait for a slot's previous occupant -- against the oracle at every checkpoint."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSD_AQL_QUEUE_SIZE="64", SSD_LIB_PATH=HOOKS_LIB, SOAK_EXPECT_PATH="aql")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_parity.py"), "harvest", "2304", "600", "50", "chains"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "soak ok" in out, out[-2000:]
+
+
 def test_shard_invariance_and_determinism():
     """Seeds derive from the GLOBAL env index: 4096 envs in one handle == 4 handles of 1024 envs with
     env_index_base = 0, 1024, ...  (the partitioning of configs[3], on one GPU); and the same seed twice
