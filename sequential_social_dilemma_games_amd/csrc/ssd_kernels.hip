@@ -74,7 +74,11 @@ __device__ __forceinline__ uint32_t phase_key(uint32_t key, uint32_t t, uint32_t
 }
 // (the two halves of phase_key: the first is the same for every stream of a step -- computed once per pass, on the scalar unit)
 __device__ __forceinline__ uint32_t step_key(uint32_t key, uint32_t t) { return mix32(key ^ t); }
+#ifdef SSD_EXP_NOSTREAMKEY   // (experiment switch, wrong results: the upper bound of what cheaper stream keys could give)
+__device__ __forceinline__ uint32_t stream_key(uint32_t skey, uint32_t stream) { return skey ^ (stream * 0x9E3779B9u); }
+#else
 __device__ __forceinline__ uint32_t stream_key(uint32_t skey, uint32_t stream) { return mix32(skey ^ stream); }
+#endif
 __device__ __forceinline__ uint32_t draw(uint32_t pkey, uint32_t index) { return mix32(pkey ^ index); }
 __device__ __forceinline__ uint32_t randint(uint32_t u, uint32_t n) { return __umulhi(u, n); }
 
@@ -825,6 +829,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             // (every keyed draw of this pass -- actions, move shuffle, apples, waste coins and order -- hashes (key, t) first: once,
             // here, instead of once per stream inside whatever branch needs one: 12 scalar instructions per further stream)
             const uint32_t skey = step_key(key, t);
+            // (measured and dropped, round 4: the second half for ALL streams at once on the vector unit -- lane s hashing stream s, a
+            // needed stream reading its lane: 12 vector instructions instead of 12 scalar ones per stream.  A hash is three 32-bit
+            // multiplies, quarter rate on the vector unit: with the pairwise test below on DPP as well, Harvest 5.13 -> 5.33 us per
+            // step; the scalar form stays)
+            auto stream_key_of = [&](uint32_t stream) -> uint32_t { return stream_key(skey, stream); };
             if (is_step) {
                 // ---- actions (map_env.py:171-173) ----
                 constexpr int kNumActions = GAME == 0 ? 8 : 9;   // harvest.py:44, cleanup.py:70
@@ -834,7 +843,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     const bool bad = is_agent && (act < -1 || act >= kNumActions);
                     if (ballot(bad)) { status |= kStBadAction; if (bad) act = -1; }
                 } else if (roll || p.num_actions_random > 0) {   // rollout.py:64-65 uniform random actions
-                    const uint32_t pk = stream_key(skey, kAction);
+                    const uint32_t pk = stream_key_of(kAction);
                     if (is_agent) {
                         act = (int)randint(draw(pk, (uint32_t)lane), (uint32_t)p.num_actions_random);
                         if (!roll && p.actions_out) p.actions_out[eN + lane] = act;
@@ -887,12 +896,45 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 // reference algorithm in full.
                 const uint64_t agents_m = N >= 64 ? ~0ull : bit((uint32_t)N) - 1;
                 uint64_t clashm = 0, dupm = 0;                   // lanes (!= j) whose target is agent j's cell or mover j's target
-                for (int j = 0; j < N; ++j) {
-                    const uint32_t cj = rl(cell, j), tj = rl(tcell, j);
-                    const uint64_t on_cell = ballot(tcell == cj), on_target = (((M >> j) & 1) ? ballot(tcell == tj) : 0ull) & ~bit(j);
-                    clashm |= (on_cell & ~bit(j)) | on_target;
-                    dupm |= on_target;
+#ifndef SSD_EXP_NOCLASH   // (experiment switch, wrong results: the upper bound of what a cheaper clash test could give)
+                // The pairwise comparison.  Up to 16 agents sit in one row of 16 lanes, so lane i can look at lane (i + k) mod 16's
+                // cell and target with DPP row rotations, k = 1 .. 15 (never at itself; lanes that hold no agent / no mover carry
+                // values no target can equal): its clash bit is "some xor came out zero", one min per partner, all on the vector
+                // unit.  As a loop over the agents with v_readlane + scalar mask arithmetic the same test was 13 instructions per
+                // agent, 9 of them scalar -- on the unit the CU's four SIMDs share; its upper bound (no test at all, no slow path)
+                // measured 5.19 -> 5.00 us per step for Harvest and 7.05 -> 6.22 for Cleanup 48 x 36 with ten agents.  The exact masks
+                // the slow path wants (who shares WHICH target) are still made by the loop, there.
+                // In the ROLLOUT kernel only: there it pays (fused 3.39 -> 3.29 us per step: that kernel is bound by issue slots, the
+                // scalar unit's first); in the per-step kernels of the chains the same change costs (Harvest 5.13 -> 5.32, Cleanup
+                // 48 x 36 7.08 -> 7.21, alternating fresh processes): their env waves are a chain of dependent operations, and
+                // 24 - 45 dependent vector instructions with DPP hazards are a longer one than the loop's scalar arithmetic.
+                bool exact_loop = !roll || (NA == 0 && N > 16);
+                if (!exact_loop) {
+                    const uint32_t cellx = is_agent ? cell : 0xFFFFFFFEu, tcellm = mover ? tcell : 0xFFFFFFFFu;
+                    uint32_t nearest = 0xFFFFFFFFu;
+                    // partners at distance d = 1 .. N - 1 in either direction: rotations d and 16 - d (row_ror:k = DPP control 0x120 + k)
+                    constexpr int kN = NA > 0 ? NA : 16;
+#define SSD_LOOK(k)                                                                                                            \
+    if constexpr ((k) < kN || 16 - (k) < kN) {                                                                                  \
+        const uint32_t pc = SSD_DPP(0, cellx, 0x120 + (k), false), pt = SSD_DPP(0, tcellm, 0x120 + (k), false);                \
+        nearest = umin(nearest, umin(tcell ^ pc, tcell ^ pt));                                                                  \
+    }
+                    SSD_LOOK(1) SSD_LOOK(2) SSD_LOOK(3) SSD_LOOK(4) SSD_LOOK(5) SSD_LOOK(6) SSD_LOOK(7) SSD_LOOK(8)
+                    SSD_LOOK(9) SSD_LOOK(10) SSD_LOOK(11) SSD_LOOK(12) SSD_LOOK(13) SSD_LOOK(14) SSD_LOOK(15)
+#undef SSD_LOOK
+                    clashm = ballot(is_agent & (nearest == 0u));
+                    exact_loop = (clashm & M) != 0;              // a mover clashes: the slow path, with exact masks
                 }
+                if (exact_loop) {
+                    clashm = 0;
+                    for (int j = 0; j < N; ++j) {
+                        const uint32_t cj = rl(cell, j), tj = rl(tcell, j);
+                        const uint64_t on_cell = ballot(tcell == cj), on_target = (((M >> j) & 1) ? ballot(tcell == tj) : 0ull) & ~bit(j);
+                        clashm |= (on_cell & ~bit(j)) | on_target;
+                        dupm |= on_target;
+                    }
+                }
+#endif
                 // (1.75 % of the envs of a random-action Harvest step; upper bound of what a faster slow path could give -- every env
                 // taking the fast path, wrong results --: 5.13 against 5.35 us per 4096-env step; Cleanup: no difference)
                 const bool slow = (clashm & M) != 0;
@@ -918,7 +960,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                                 if ((M >> a) & 1) { if (lane == cnt) perm = a; ++cnt; }
                             }
                         }
-                        const uint32_t pk = stream_key(skey, kMove);
+                        const uint32_t pk = stream_key_of(kMove);
                         // draw i is keyed by i alone: lane i computes its own, all at once; only the swaps are sequential
                         const uint32_t jv = randint(draw(pk, (uint32_t)lane), (uint32_t)lane + 1);
                         for (int i = nm - 1; i >= 1; --i) {      // :421-423 np.random.shuffle = Fisher-Yates from the end
@@ -1268,7 +1310,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 // The LDS reads of one list entry are unconditional (padding entries point at an interior
                 // cell), so they go out as one independent batch.
                 uint64_t spawn_bits = 0;                                                // bit j: list entry lane + 64*j gets an apple
-                const uint32_t pk_apple = stream_key(skey, kApple);
+                const uint32_t pk_apple = stream_key_of(kApple);
                 const int a_iters = (n_apple + 63) >> 6;
                 const uint32_t safe = (uint32_t)(WP + 1);                               // cell (1,1)
                 uint32_t waste_cell = 0xFFFFFFFFu;
@@ -1387,7 +1429,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     if (thr_w) {
                         // :144-153 shuffled scan, first non-'H' point whose coin succeeds (at most one per step):
                         // order = ascending (ORDER draw, cell), coin keyed by cell.
-                        const uint32_t pk_coin = stream_key(skey, kWasteCoin), pk_ord = stream_key(skey, kWasteOrder);
+                        const uint32_t pk_coin = stream_key_of(kWasteCoin), pk_ord = stream_key_of(kWasteOrder);
                         bool has = false;
                         uint32_t bh = 0, bl = 0;
                         auto waste = [&](uint32_t ce, bool valid) {

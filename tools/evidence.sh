@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/evidence.sh ROUND [quick] -- run ON THE GPU BOX: the long parity runs of the final build whose logs are kept under profiles/:
+# tools/evidence.sh ROUND [1|2] -- run ON THE GPU BOX (part 1: fuzz + the shipped maps' soaks; part 2: the enlarged maps and the large output rings; none: both): the long parity runs of the final build whose logs are kept under profiles/:
 # the fuzz tool (400 random configurations through every API path, ssd_rollout_actions with action / order rings included) and the
 # soak (4096 envs x 5000 steps per game as rollout chains -- the library's own dispatch queues, coherent, split --, the same with
 # caller-supplied actions (ssd_rollout_actions: chains and fused), and with the test-hook library's SSD_AQL_ALTERNATE=1, which
@@ -8,6 +8,8 @@ ROUND=${1:?round tag, e.g. r04}
 cd $GRAFT_REPO_ROOT
 D=gpurun_out/${ROUND}_evidence
 mkdir -p $D
+PART=${2:-0}
+if [ "$PART" != "2" ]; then
 python3 tools/fuzz_parity.py 400 0 2>&1 | grep -v amdgpu.ids | tee $D/fuzz_400_seed0.log | tail -3
 FUZZ_BIG=1 python3 tools/fuzz_parity.py 100 7 2>&1 | grep -v amdgpu.ids | tee $D/fuzz_big_100_seed7.log | tail -2
 for g in harvest cleanup; do
@@ -17,6 +19,8 @@ for g in harvest cleanup; do
   SSD_LIB_PATH=sequential_social_dilemma_games_amd/libssd_hip_testhooks.so SSD_AQL_ALTERNATE=1 SSD_AQL_ALWAYS_FORK=1 python3 tools/soak_parity.py $g 4096 3000 250 chains 2>&1 | grep -v amdgpu.ids | tee $D/soak_${g}_chains_alternate.log | tail -2
   python3 tools/soak_parity.py $g 4096 3000 250 fused 2>&1 | grep -v amdgpu.ids | tee $D/soak_${g}_fused.log | tail -2
 done
+fi
+if [ "$PART" = "1" ]; then exit 0; fi
 # ... and the enlarged maps' own kernels (BASELINE.json's 25x38 label; configs[4]'s per-GPU share)
 python3 tools/soak_parity.py harvest25x38 4096 2000 250 chains 2>&1 | grep -v amdgpu.ids | tee $D/soak_harvest25x38_chains.log | tail -2
 python3 tools/soak_parity.py cleanup48x36 2048 2000 250 chains 2>&1 | grep -v amdgpu.ids | tee $D/soak_cleanup48x36_chains.log | tail -2
