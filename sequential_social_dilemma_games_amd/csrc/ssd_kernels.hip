@@ -926,28 +926,50 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     exact_loop = (clashm & M) != 0;              // a mover clashes: the slow path, with exact masks
                 }
                 if (exact_loop) {
+                    // (a target that is not a mover's is a value no target equals: the loop then has no "is j a mover" test -- a
+                    // scalar bit test and a branch per agent -- and the second mask, which only the slow path reads, is made there:
+                    // 7 instructions per agent instead of 13)
+                    const uint32_t tcellm = mover ? tcell : 0xFFFFFFFFu;
                     clashm = 0;
                     for (int j = 0; j < N; ++j) {
-                        const uint32_t cj = rl(cell, j), tj = rl(tcell, j);
-                        const uint64_t on_cell = ballot(tcell == cj), on_target = (((M >> j) & 1) ? ballot(tcell == tj) : 0ull) & ~bit(j);
-                        clashm |= (on_cell & ~bit(j)) | on_target;
-                        dupm |= on_target;
+                        const uint32_t cj = rl(cell, j), tj = rl(tcellm, j);
+                        clashm |= (ballot(tcell == cj) | ballot(tcell == tj)) & ~bit(j);
                     }
                 }
 #endif
                 // (1.75 % of the envs of a random-action Harvest step; upper bound of what a faster slow path could give -- every env
                 // taking the fast path, wrong results --: 5.13 against 5.35 us per 4096-env step; Cleanup: no difference)
+#ifdef SSD_EXP_NOSLOW       // (experiment switch, wrong results: every env takes the fast path; the pairwise test stays)
+                const bool slow = false;
+#elif defined(SSD_EXP_NOSLOW_KEEPCODE)   // (... and the same with the slow path's code still in the kernel, never entered)
+                const bool slow = (clashm & M) != 0 && p.n_spawn < 0;
+#else
                 const bool slow = (clashm & M) != 0;
+#endif
                 SSD_NOTE(12, slow ? 1 : 0);
-                if (!slow) {
+                // (likelihood hints: the rare arms -- contested moves, beams that land one after the other, long lists -- go out of line,
+                // the common path falls through)
+                if (__builtin_expect(!slow, 1)) {
                     if (mover) cell = tcell;
                     all_apart = (clashm & agents_m) == 0;        // nobody's target is anybody else's target or cell
+#ifdef SSD_EXP_ALLAPART     // (experiment switch, wrong results: the consume phase never compares the agents' cells)
+                    all_apart = true;
+#endif
                 } else {                                         // :415 (M != 0 here)
                     __builtin_amdgcn_s_setprio(3);               // the slowest waves of a launch come through here (1-2 % of the envs)
                     uint64_t Hm = M;                             // ids that still have an entry in agent_moves
                     // :424-491 cells wanted by several agents, in lexicographic order (np.unique, axis=0): visited in
                     // ascending cell order (scalar min over the few lanes involved).  The shuffle of :421-423 only
                     // decides who wins such a cell, so it is only computed when there is one (draws are counter-keyed).
+                    // These waves are the tail of their launch: forced onto the fast path (wrong results; the code still in the
+                    // kernel) Cleanup 48 x 36 with ten agents steps in 6.47 instead of 6.98 us, Harvest in 5.12 instead of 5.15.
+                    // (Measured and dropped, round 4: what the two loops below ask -- do two movers share a target, who stands on
+                    // each agent's target, do two agents share a cell -- asked through LDS instead, every agent marking its cell
+                    // and every mover its target in the two still-empty layers: ~12 instructions and ONE round trip instead of
+                    // N x 15 instructions, bit-exact -- and slower: 7.00 -> 7.12 / 5.11 -> 5.24 us per step.  Under this load a
+                    // dependent trip through LDS costs a wave more than a hundred scalar instructions do.)
+                    for (int j = 0; j < N; ++j)                  // lanes (!= j) whose target is mover j's target
+                        if ((M >> j) & 1) dupm |= ballot(tcell == rl(tcell, j)) & ~bit(j);
                     uint64_t todo = dupm & M;
                     SSD_NOTE(12, todo ? 2 : 1);
                     if (todo) {
@@ -1019,6 +1041,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                                 const bool waiting = st == 2;
                                 st = (waiting & (s2 != 2)) ? s2 : st;
                                 nx = (waiting & (s2 == 2)) ? n2 : nx;
+                                // (these waves are their launch's tail, and a chain of waiting agents is rarely longer than one: a
+                                // round is two dependent trips through the LDS crossbar -- stop when nobody waits any more)
+                                if (!ballot(st == 2)) break;
                             }
                             if (ballot(st == 2)) {                                      // still waiting: on a cycle
                                 const int back = __builtin_amdgcn_ds_bpermute(nx0, nx0);    // my target's target ...
@@ -1207,7 +1232,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                                 beams_in_regs = false;
                                 break;
                             }
-                            if (landed) {
+                            if (__builtin_expect(landed, 0)) {
                                 // Keep the geometry (cell of every lane, first wall of every ray -- walls do not move) and let
                                 // the slots land in order: a CLEAN slot j re-reads its cells from the map as slots < j left it
                                 // and finds its stops again; every slot marks, CLEAN ones clean.  (Every mask byte is overwritten:
@@ -1356,7 +1381,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                             total += __builtin_popcountll(em[j]);
                         }
                     }
-                    if (a_iters <= kLR && total <= 64) {
+                    if (__builtin_expect(a_iters <= kLR && total <= 64, 1)) {
                         // Usual case: at most 64 candidates among the (up to 512) apple points.  Compact them through
                         // 128 B of LDS scratch so that ONE pass of lanes does the stencil + draw instead of three.
                         if (total) {
