@@ -1381,7 +1381,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                             total += __builtin_popcountll(em[j]);
                         }
                     }
+#ifdef SSD_EXP_NOCOMPACT    // (experiment switch: every lane evaluates its own list entries -- no compaction, one LDS round trip fewer)
+                    if (false) {
+#else
                     if (__builtin_expect(a_iters <= kLR && total <= 64, 1)) {
+#endif
                         // Usual case: at most 64 candidates among the (up to 512) apple points.  Compact them through
                         // 128 B of LDS scratch so that ONE pass of lanes does the stencil + draw instead of three.
                         if (total) {
