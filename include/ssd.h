@@ -198,7 +198,7 @@ int ssd_rollout_path(const ssd_env *env);
  * of the pool at once, joined through the null stream the way a rollout call is joined, timed against the pool's first queue
  * alone (MI355X: ~50 us with a hardware queue slot each, ~140 us when time-sliced); and a burst of HIP launches against its figure
  * from before the pool existed.  A queue whose arrival makes the concurrent burst more than 1.6 x (+ 10 us) slower, or the HIP burst
- * more than 2.5 x (+ 20 us), is destroyed again and the pool stays at the size that was fine for the life of the process
+ * more than 2.5 x (+ 20 us) -- in two measurements, the second after the device has drained -- is destroyed again and the pool stays at the size that was fine for the life of the process
  * (SSD_PATH_QUEUE_DROPPED, bits 12..14 of ssd_rollout_path); an automatic chain count follows the smaller pool.  If already the
  * FIRST queue's burst takes more than 100 us, the process is past the cliff without the library (a host application with four
  * busy streams): the library then holds no queue at all and an automatic chain count is 1 -- the launches go to the caller's own

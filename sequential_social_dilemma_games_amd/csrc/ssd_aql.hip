@@ -465,21 +465,31 @@ static bool probe_pool_queue(DeviceCtx *c, Queue *Q, int index) {
     for (int i = 0; i < index && i < kPoolSlots - 1; ++i) if (c->pool[i]) qs[nq++] = c->pool[i];
     qs[nq++] = Q;
     (void)concurrent_burst_us(c, qs, nq, 2);              // (first dispatches of a new queue: not timed)
-    double qv[kBurstReps], hv[kBurstReps];
-    for (double &x : qv) x = concurrent_burst_us(c, qs, nq, kBurst);
-    for (double &x : hv) x = hip_burst_us(c, kBurst);
-    std::sort(qv, qv + kBurstReps); std::sort(hv, hv + kBurstReps);
-    const double q_us = qv[0] < 0 ? -1 : qv[kBurstReps / 2], h_us = hv[0] < 0 ? -1 : hv[kBurstReps / 2];
-    c->q_burst_last_us = q_us; c->hip_burst_last_us = h_us;
-    if (index == 0) c->q_burst_base_us = q_us;
-    char msg[320];
-    snprintf(msg, sizeof msg, "probe: %d queue(s) at once, %d dispatches each: %.1f us (the first queue alone %.1f); %d HIP launches %.1f us (before the pool %.1f)",
-             nq, kBurst, q_us, c->q_burst_base_us, kBurst, h_us, c->hip_burst_base_us);
-    say(msg);
-    if (q_us < 0 || h_us < 0 || c->hip_burst_base_us <= 0) return true;           // (no figures: no verdict)
-    const bool hip_slow = h_us > 2.5 * c->hip_burst_base_us + 20.0;
-    const bool q_slow = index > 0 ? (c->q_burst_base_us > 0 && q_us > 1.6 * c->q_burst_base_us + 10.0) : (q_us > 100.0);
-    return !(hip_slow || q_slow);
+    // (the verdict is permanent for the process, so one noisy moment -- another handle's rollout in flight, a co-tenant --
+    // must not decide it: a queue that fails is measured once more after the device has drained, and only a second failure counts.
+    // The first queue's bound stays the absolute MI355X figure: measured against the process's own HIP burst it would vanish in
+    // exactly the case it is for -- a process past the cliff already has a slow HIP burst too)
+    bool ok = true;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (attempt == 1 && hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+        double qv[kBurstReps], hv[kBurstReps];
+        for (double &x : qv) x = concurrent_burst_us(c, qs, nq, kBurst);
+        for (double &x : hv) x = hip_burst_us(c, kBurst);
+        std::sort(qv, qv + kBurstReps); std::sort(hv, hv + kBurstReps);
+        const double q_us = qv[0] < 0 ? -1 : qv[kBurstReps / 2], h_us = hv[0] < 0 ? -1 : hv[kBurstReps / 2];
+        c->q_burst_last_us = q_us; c->hip_burst_last_us = h_us;
+        if (index == 0) c->q_burst_base_us = q_us;
+        char msg[360];
+        snprintf(msg, sizeof msg, "probe%s: %d queue(s) at once, %d dispatches each: %.1f us (the first queue alone %.1f); %d HIP launches %.1f us (before the pool %.1f)",
+                 attempt ? " (second look)" : "", nq, kBurst, q_us, c->q_burst_base_us, kBurst, h_us, c->hip_burst_base_us);
+        say(msg);
+        if (q_us < 0 || h_us < 0 || c->hip_burst_base_us <= 0) return true;       // (no figures: no verdict)
+        const bool hip_slow = h_us > 2.5 * c->hip_burst_base_us + 20.0;
+        const bool q_slow = index > 0 ? (c->q_burst_base_us > 0 && q_us > 1.6 * c->q_burst_base_us + 10.0) : (q_us > 100.0);
+        ok = !(hip_slow || q_slow);
+        if (ok) break;
+    }
+    return ok;
 }
 
 // Queue `index` (0 .. pool_size(device) - 1) of the device's pool, created -- and probed -- on first use; nullptr if that fails or
