@@ -17,6 +17,7 @@ mask = int(sys.argv[1], 0)
 which = sys.argv[2] if len(sys.argv) > 2 else "harvest"
 E = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 40
+fused = os.environ.get("PMC_FUSED") == "1"            # the rollout kernel instead of the chains (tools/pmc_fused_phases.sh)
 game = K.GAME_CLEANUP if which.startswith("cleanup") else K.GAME_HARVEST
 amap, n = (K.cleanup_map_48x36(), 10) if which == "cleanup48x36" else (None, 5)
 eng = VecEngine(game, amap, num_envs=E, num_agents=n, seed=0)
@@ -25,11 +26,11 @@ ring = tuple(t.unsqueeze(0) for t in out)
 eng.reset(obs=out[0])
 L = _capi.lib()
 L.ssd_debug_set_skip.argtypes = [C.c_void_p, C.c_uint32]
-eng.set_rollout_chains(2)
-eng.rollout_random(8, *ring)
+eng.set_rollout_chains(1 if fused else 2)
+eng.rollout_random(8, *ring, fused=fused)
 torch.cuda.synchronize()
 L.ssd_debug_set_skip(eng._h, mask)
 for _ in range(3):
-    eng.rollout_random(steps, *ring)
+    eng.rollout_random(steps, *ring, fused=fused)
     torch.cuda.synchronize()
 print("path", eng.rollout_path())
