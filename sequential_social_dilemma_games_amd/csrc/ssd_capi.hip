@@ -1322,6 +1322,7 @@ int ssd_set_state(ssd_env *env, const int8_t *world, const int8_t *beam, const i
             SSD_HIP(env, hipMemcpy(env->p.beam, buf.data(), buf.size(), hipMemcpyHostToDevice));
         }
     }
+    std::vector<uint8_t> share;
     if ((pos || orient) && N > 0) {
         std::vector<uint32_t> ag((size_t)E * N);
         SSD_HIP(env, hipMemcpy(ag.data(), env->p.agents, ag.size() * 4, hipMemcpyDeviceToHost));
@@ -1337,17 +1338,25 @@ int ssd_set_state(ssd_env *env, const int8_t *world, const int8_t *beam, const i
             ag[i] = cell | (o << 16);
         }
         SSD_HIP(env, hipMemcpy(env->p.agents, ag.data(), ag.size() * 4, hipMemcpyHostToDevice));
+        if (pos) {                                  // hdr.w bit 31: two agents of the env share a cell (the kernel's move phase asks)
+            share.assign(E, 0);
+            for (int e = 0; e < E; ++e)
+                for (int i = 0; i < N; ++i)
+                    for (int j = i + 1; j < N; ++j)
+                        if (((ag[(size_t)e * N + i] ^ ag[(size_t)e * N + j]) & 0xFFFFu) == 0) share[e] = 1;
+        }
     }
     const bool recount = world && env->game == SSD_GAME_CLEANUP;      // the kernel keeps the grid's 'H' count in hdr.w
-    if (episode || t || recount) {
+    if (episode || t || recount || !share.empty()) {
         std::vector<uint4> hdr(E);
         SSD_HIP(env, hipMemcpy(hdr.data(), env->p.hdr, hdr.size() * sizeof(uint4), hipMemcpyDeviceToHost));
         for (int e = 0; e < E; ++e) {
             if (recount) {
                 uint32_t n = 0;
                 for (int i = 0; i < hw; ++i) n += world[(size_t)e * hw + i] == 'H';
-                hdr[e].w = (hdr[e].w & 0xFFFFu) | (n << 16);
+                hdr[e].w = (hdr[e].w & 0x8000FFFFu) | (n << 16);
             }
+            if (!share.empty()) hdr[e].w = (hdr[e].w & 0x7FFFFFFFu) | ((uint32_t)share[e] << 31);
             if (t) hdr[e].y = t[e];
             if (episode) {
                 hdr[e].z = episode[e];

@@ -60,7 +60,8 @@ struct Params {
     uint8_t *world;                // [E][S]  ASCII cells
     uint8_t *beam;                 // [E][S]  beam overlay (keep_beams only), 0 = none
     uint32_t *agents;              // [E][N]  cell | orient << 16
-    uint4 *hdr;                    // [E]     {key, t, episode, #'H' used by the last spawn pass (Cleanup)}
+    uint4 *hdr;                    // [E]     {key, t, episode, #'H' used by the last spawn pass (Cleanup) | #'H' in the grid << 16 |
+                                   //          "two agents may share a cell" << 31}
     uint32_t *status;              // [1]     SSD_ST_* bits
     // static tables in HBM (L2-resident)
     const uint8_t *reset_world;    // [S]     world right after reset_map()

@@ -639,7 +639,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // less what this step's CLEAN beams clean (cleanup.py:115 after :94-111), almost always within the window
         uint64_t thr_pa = 0, thr_pw = 0;
         if constexpr (kPre) {
-            int ti = (int)(rfl(hdr.w) >> 16) - lane;
+            int ti = (int)((rfl(hdr.w) >> 16) & 0x7FFFu) - lane;
             ti = ti < 0 ? 0 : ti;
             ti = ti < p.n_thr ? ti : p.n_thr - 1;
             thr_pa = p.thr_ca[ti]; thr_pw = p.thr_cw[ti];
@@ -684,7 +684,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // Cleanup keeps the number of 'H' cells of the stored grid in the upper half of hdr.w (the lower half is the count
         // the last spawn pass used, ssd_get_waste_count): a step only changes it by the cells its CLEAN beams clean and the
         // one waste cell it may spawn, so compute_permitted_area (cleanup.py:173-179) need not recount the grid.
-        uint32_t waste_cur = GAME == 1 ? rfl(hdr.w) >> 16 : 0u;
+        uint32_t waste_cur = GAME == 1 ? (rfl(hdr.w) >> 16) & 0x7FFFu : 0u;
+        // Bit 31 of hdr.w: "two agents may share a cell" in the stored state (possible only after a contested cell was entered
+        // while its occupant was still there, map_env.py:480-483; never after a reset; ssd_set_state computes it).  Exact after
+        // every step's consume phase; lets the move phase of a step that finds its agents apart skip the pair-by-pair look.
+        bool share = (rfl(hdr.w) >> 31) != 0u;
         // (measured and dropped, round 3: the grid written back right after the beams -- its stores then overlap the spawn pass --
         // and only the 16-byte pieces the spawn pass changed written again at the end: Harvest 4096 envs 5.50 against 5.50 us per
         // step (a first pair of runs said 5.43 against 5.54: box noise), 2048 envs 4.68 against 4.61, 8192 envs 10.56 against
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 if (is_agent) cstore(ga + eN + lane, cell | (orient << 16) | top_bit | (lane == 0 ? render_flags : 0u));
                 {   // the header's four words, one per lane: three v_writelane into a register that holds the fourth everywhere (as a
                     // chain of selects on the lane index the compiler made ~20 instructions of nested exec-mask branches of it)
-                    uint32_t hw = waste_last | (waste_cur << 16);
+                    uint32_t hw = waste_last | (waste_cur << 16) | (share ? 1u << 31 : 0u);
                     asm("v_writelane_b32 %0, %1, 0" : "+v"(hw) : "s"(key));
                     asm("v_writelane_b32 %0, %1, 1" : "+v"(hw) : "s"(t));
                     asm("v_writelane_b32 %0, %1, 2" : "+v"(hw) : "s"(episode));
@@ -742,7 +746,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     *reinterpret_cast<uint4 *>(p.beam + (size_t)e * S + i) = *reinterpret_cast<const uint4 *>(s_beam + i);
             }
             if (is_agent) a_agents[eN + lane] = cell | (orient << 16);
-            if (lane == 0) a_hdr[e] = make_uint4(key, t, episode, waste_last | (waste_cur << 16));
+            if (lane == 0) a_hdr[e] = make_uint4(key, t, episode, waste_last | (waste_cur << 16) | (share ? 1u << 31 : 0u));
             if (status && lane == 0) atomicOr(p.status, status);
         };
         // ---- One pass = one reset or one step of the env.  A step / reset / observe launch makes one pass.  A rollout
@@ -818,6 +822,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     s_occ[chosen] = agent_glyph((uint32_t)i);    // all lanes, same address, same value
                     wave_sync();
                 }
+                share = (status & kStNoSpawn) != 0u;             // spawn points are handed out one agent per point
             }
 
             SSD_STAMP(1);   // state loaded
@@ -925,12 +930,30 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     clashm = ballot(is_agent & (nearest == 0u));
                     exact_loop = (clashm & M) != 0;              // a mover clashes: the slow path, with exact masks
                 }
+                // Ten agents (per-step kernels): a contested move is no longer rare (Cleanup 48 x 36: every launch has such waves in
+                // its tail), so the loop also keeps what the contested path would otherwise ask again with two more loops over the
+                // agents: the two masks apart, and -- per lane -- who stands on its target.
+#ifndef SSD_EXP_FOLD5       // (experiment switch: the five-agent kernels too)
+#define SSD_EXP_FOLD5 0
+#endif
+                constexpr bool kFold = !roll && (NA == 10 || (SSD_EXP_FOLD5 && NA == 5));
+                int occ_fold = -1;
                 if (exact_loop) {
                     // (a target that is not a mover's is a value no target equals: the loop then has no "is j a mover" test -- a
                     // scalar bit test and a branch per agent -- and the second mask, which only the slow path reads, is made there:
                     // 7 instructions per agent instead of 13)
                     const uint32_t tcellm = mover ? tcell : 0xFFFFFFFFu;
                     clashm = 0;
+                    if constexpr (kFold) {
+                        for (int j = 0; j < N; ++j) {
+                            const uint32_t cj = rl(cell, j), tj = rl(tcellm, j);
+                            const bool on = tcell == cj;
+                            clashm |= ballot(on) & ~bit(j);
+                            dupm |= ballot(tcell == tj) & ~bit(j);
+                            occ_fold = on ? j : occ_fold;
+                        }
+                        clashm |= dupm;
+                    } else
                     for (int j = 0; j < N; ++j) {
                         const uint32_t cj = rl(cell, j), tj = rl(tcellm, j);
                         clashm |= (ballot(tcell == cj) | ballot(tcell == tj)) & ~bit(j);
@@ -949,12 +972,52 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                 SSD_NOTE(12, slow ? 1 : 0);
                 // (likelihood hints: the rare arms -- contested moves, beams that land one after the other, long lists -- go out of line,
                 // the common path falls through)
+                // :494-543 for agents on cells of their own whose pending moves have targets of their own: "a waits for the agent on
+                // its target" is a graph of disjoint paths and cycles, and the pass loop comes out as: a path moves as a whole iff its
+                // head's target is free; it stays as a whole if it ends at an agent that is not moving; a 2-cycle (swap, :524-530)
+                // stays; longer cycles rotate (:540-543).  Resolved by pointer jumping over lanes, ceil(log2 N) rounds.
+                // `pend`: the lane has a pending move away from its cell; `occ`: the agent on its target (< 0: none).
+                auto resolve_chains = [&](const bool pend, const int occ) {
+                    int st = pend ? (occ < 0 ? 1 : 2) : 0;       // 0 stays, 1 moves, 2 waits for lane `nx`
+                    // Most often nobody waits for an agent that is itself about to move (the agent in the way is firing,
+                    // turning, blocked by a wall or staying): then free targets are taken and the rest stay, no jumping.
+                    const uint64_t pendm = ballot(pend);
+                    if (ballot((st == 2) & (((pendm >> (occ & 63)) & 1ull) != 0))) {
+                        const int nx0 = (occ & 63) << 2;
+                        int nx = nx0;
+                        for (int r = 1; r < N; r <<= 1) {
+                            const int s2 = __builtin_amdgcn_ds_bpermute(nx, st), n2 = __builtin_amdgcn_ds_bpermute(nx, nx);
+                            const bool waiting = st == 2;
+                            st = (waiting & (s2 != 2)) ? s2 : st;
+                            nx = (waiting & (s2 == 2)) ? n2 : nx;
+                            // (these waves are their launch's tail, and a chain of waiting agents is rarely longer than one: a
+                            // round is two dependent trips through the LDS crossbar -- stop when nobody waits any more)
+                            if (!ballot(st == 2)) break;
+                        }
+                        if (ballot(st == 2)) {                   // still waiting: on a cycle
+                            const int back = __builtin_amdgcn_ds_bpermute(nx0, nx0);    // my target's target ...
+                            st = st == 2 ? (back == (lane << 2) ? 0 : 1) : st;          // ... is me: a swap
+                        }
+                    }
+                    return st == 1;
+                };
+                // (kFold) some mover's target is taken, but no two movers want the same cell and no cell holds two agents: the loop
+                // above has everything the chains need -- no shuffle, no second and third loop over the agents, and the agents are
+                // apart afterwards (the consume phase's loop over them goes too)
+                const bool chains_only = kFold && slow && (dupm & M) == 0 && !share;
                 if (__builtin_expect(!slow, 1)) {
                     if (mover) cell = tcell;
                     all_apart = (clashm & agents_m) == 0;        // nobody's target is anybody else's target or cell
 #ifdef SSD_EXP_ALLAPART     // (experiment switch, wrong results: the consume phase never compares the agents' cells)
                     all_apart = true;
 #endif
+                } else if (chains_only) {
+#ifdef SSD_EXP_MUT_CHAINS   // (mutation switch, wrong results: proves that the tests reach this path)
+                    if (mover) cell = tcell;
+#else
+                    if (resolve_chains(mover & (tcell != cell), occ_fold)) cell = tcell;
+#endif
+                    all_apart = true;
                 } else {                                         // :415 (M != 0 here)
                     __builtin_amdgcn_s_setprio(3);               // the slowest waves of a launch come through here (1-2 % of the envs)
                     uint64_t Hm = M;                             // ids that still have an entry in agent_moves
@@ -968,28 +1031,57 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     // and every mover its target in the two still-empty layers: ~12 instructions and ONE round trip instead of
                     // N x 15 instructions, bit-exact -- and slower: 7.00 -> 7.12 / 5.11 -> 5.24 us per step.  Under this load a
                     // dependent trip through LDS costs a wave more than a hundred scalar instructions do.)
+                    if constexpr (!kFold)
                     for (int j = 0; j < N; ++j)                  // lanes (!= j) whose target is mover j's target
                         if ((M >> j) & 1) dupm |= ballot(tcell == rl(tcell, j)) & ~bit(j);
                     uint64_t todo = dupm & M;
                     SSD_NOTE(12, todo ? 2 : 1);
+                    bool entered_taken = false;                  // a contested cell was entered while an agent stood on it
                     if (todo) {
                         const int nm = __builtin_popcountll(M);
                         uint32_t perm = 0;                       // lane k: k-th entry of the (shuffled) zipped list
-                        {
-                            int cnt = 0;
-                            for (int k = 0; k < nord; ++k) {
-                                const uint32_t a = has_order ? rl(ordv, k) : (uint32_t)k;
-                                if ((M >> a) & 1) { if (lane == cnt) perm = a; ++cnt; }
-                            }
-                        }
                         const uint32_t pk = stream_key_of(kMove);
                         // draw i is keyed by i alone: lane i computes its own, all at once; only the swaps are sequential
                         const uint32_t jv = randint(draw(pk, (uint32_t)lane), (uint32_t)lane + 1);
-                        for (int i = nm - 1; i >= 1; --i) {      // :421-423 np.random.shuffle = Fisher-Yates from the end
-                            const uint32_t j = rl(jv, i);
-                            const uint32_t vi = rl(perm, i), vj = rl(perm, j);
-                            if (lane == i) perm = vj;
-                            if (lane == (int)j) perm = vi;
+                        if constexpr (kFold) {
+                            // The unshuffled list: the movers in action order -- without an order array, mover a is entry
+                            // (number of movers below a): sent there through the crossbar (the others send to lanes past the list).
+                            if (!has_order) {
+                                const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
+                                perm = (uint32_t)__builtin_amdgcn_ds_permute((int)((mover ? r : 32u + ((uint32_t)lane & 31u)) << 2), lane);
+                            } else {
+                                int cnt = 0;
+                                for (int k = 0; k < nord; ++k) {
+                                    const uint32_t a = rl(ordv, k);
+                                    if ((M >> a) & 1) { if (lane == cnt) perm = a; ++cnt; }
+                                }
+                            }
+                            // :421-423 np.random.shuffle = Fisher-Yates from the end: for i = nm - 1 .. 1 swap entries i and j_i.  Lane k
+                            // follows position k BACKWARDS through the swaps (the last one first) to the entry that ends there: a chain
+                            // of vector selects against swap partners that are all read out beforehand -- as swaps of the list itself
+                            // every round was three v_readlane + two selects, each waiting for the one before.
+                            const uint32_t jeff = lane < nm ? jv : (uint32_t)lane;       // (past the list: a swap with itself)
+                            uint32_t pos = (uint32_t)lane;
+#pragma unroll
+                            for (int i = 1; i < NA; ++i) {
+                                const uint32_t j = rl(jeff, i);
+                                pos = pos == (uint32_t)i ? j : (pos == j ? (uint32_t)i : pos);
+                            }
+                            perm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos << 2), (int)perm);
+                        } else {
+                            {
+                                int cnt = 0;
+                                for (int k = 0; k < nord; ++k) {
+                                    const uint32_t a = has_order ? rl(ordv, k) : (uint32_t)k;
+                                    if ((M >> a) & 1) { if (lane == cnt) perm = a; ++cnt; }
+                                }
+                            }
+                            for (int i = nm - 1; i >= 1; --i) {  // :421-423 np.random.shuffle = Fisher-Yates from the end
+                                const uint32_t j = rl(jv, i);
+                                const uint32_t vi = rl(perm, i), vj = rl(perm, j);
+                                if (lane == i) perm = vj;
+                                if (lane == (int)j) perm = vi;
+                            }
                         }
                         while (todo) {
                             uint32_t nxt = 0xFFFFFFFFu;
@@ -1007,12 +1099,26 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                             }
                             if (cell_free) {                     // :480-483 first contender in shuffled order moves NOW
                                 uint32_t w = 0;
-                                for (int k = 0; k < nm; ++k) { w = rl(perm, k); if ((Cm >> w) & 1) break; }
+                                if constexpr (kFold) {           // (the list's first entry that is a contender)
+                                    const uint64_t firstm = ballot(lane < nm && ((Cm >> (perm & 63u)) & 1ull) != 0);
+                                    w = rl(perm, __builtin_ctzll(firstm));
+                                    // the agent that waited for the winner's cell finds it empty
+                                    occ_fold = occ_fold == (int)w ? -1 : occ_fold;
+                                    entered_taken |= Pm != 0;
+                                } else {
+                                    for (int k = 0; k < nm; ++k) { w = rl(perm, k); if ((Cm >> w) & 1) break; }
+                                }
                                 if (lane == (int)w) cell = nxt;
                             }
                             if (__builtin_amdgcn_inverse_ballot_w64(Cm)) mvcell = cell;   // :486-491 every contender's move becomes "stay"
                         }
                     }
+                    // (kFold) agents that started apart, no contested cell entered over its occupant: they are still apart, and
+                    // "who stands on my target" is what the loop at the top found (less the winners' old cells): straight to the chains
+                    if (kFold && !share && !entered_taken) {
+                        if (resolve_chains(mover & (mvcell != cell), occ_fold)) cell = mvcell;
+                        all_apart = true;
+                    } else {
                     // :494-543 remaining moves: chains, swaps, cycles.  Who stands on each agent's target, and does any cell
                     // hold two agents (possible after a contested cell was entered while its occupant was still there)?
                     uint64_t overlap = 0;
@@ -1024,33 +1130,8 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     }
                     if (!overlap) {
                         // Usual case: every cell holds at most one agent and (after the step above) no two pending moves
-                        // share a target, so "a waits for the agent on its target" is a graph of disjoint paths and cycles,
-                        // and the pass loop of :494-543 comes out as: a path moves as a whole iff its head's target is free;
-                        // it stays as a whole if it ends at an agent that is not moving; a 2-cycle (swap, :524-530) stays;
-                        // longer cycles rotate (:540-543).  Resolved by pointer jumping over lanes, ceil(log2 N) rounds.
-                        const bool pend = __builtin_amdgcn_inverse_ballot_w64(Hm) & (mvcell != cell);
-                        int st = pend ? (occ_of_target < 0 ? 1 : 2) : 0;                // 0 stays, 1 moves, 2 waits for lane `nx`
-                        // Most often nobody waits for an agent that is itself about to move (the agent in the way is firing,
-                        // turning, blocked by a wall or staying): then free targets are taken and the rest stay, no jumping.
-                        const uint64_t pendm = ballot(pend);
-                        if (ballot((st == 2) & (((pendm >> (occ_of_target & 63)) & 1ull) != 0))) {
-                            const int nx0 = (occ_of_target & 63) << 2;
-                            int nx = nx0;
-                            for (int r = 1; r < N; r <<= 1) {
-                                const int s2 = __builtin_amdgcn_ds_bpermute(nx, st), n2 = __builtin_amdgcn_ds_bpermute(nx, nx);
-                                const bool waiting = st == 2;
-                                st = (waiting & (s2 != 2)) ? s2 : st;
-                                nx = (waiting & (s2 == 2)) ? n2 : nx;
-                                // (these waves are their launch's tail, and a chain of waiting agents is rarely longer than one: a
-                                // round is two dependent trips through the LDS crossbar -- stop when nobody waits any more)
-                                if (!ballot(st == 2)) break;
-                            }
-                            if (ballot(st == 2)) {                                      // still waiting: on a cycle
-                                const int back = __builtin_amdgcn_ds_bpermute(nx0, nx0);    // my target's target ...
-                                st = st == 2 ? (back == (lane << 2) ? 0 : 1) : st;      // ... is me: a swap
-                            }
-                        }
-                        if (st == 1) cell = mvcell;
+                        // share a target: resolve_chains
+                        if (resolve_chains(__builtin_amdgcn_inverse_ballot_w64(Hm) & (mvcell != cell), occ_of_target)) cell = mvcell;
                     } else
                     while (Hm) {
                         const uint32_t snap_cell = cell, snap_mv = mvcell;              // agent_by_pos (:495), moves_copy (:498)
@@ -1082,6 +1163,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                             if (__builtin_amdgcn_inverse_ballot_w64(Hm)) cell = mvcell;
                             break;
                         }
+                    }
                     }
                 }
             }
@@ -1119,6 +1201,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     lowest |= (here & (bit(j) - 1)) ? 0ull : bit(j);
                     highest |= ((here >> j) >> 1) ? 0ull : bit(j);
                 }
+                share = highest != agents;                       // (the header's bit for the next step)
                 const bool eats = is_step & __builtin_amdgcn_inverse_ballot_w64(lowest) & (s_world[cell] == 'A');
                 if (eats) { s_world[cell] = ' '; rew += 1; }
                 if (__builtin_amdgcn_inverse_ballot_w64(highest)) s_occ[cell] = agent_glyph((uint32_t)lane);

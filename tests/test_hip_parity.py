@@ -661,6 +661,66 @@ def test_cleanup_steps_with_many_shooters(which, mode):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", ["calls", "chains", "fused"])
+@pytest.mark.parametrize("which", ["cleanup48x36", "cleanup25x18", "harvest"])
+def test_ten_agents_crowded_moves(which, mode):
+    """Ten agents that mostly MOVE, from crowded starts: targets that are taken, chains of agents following each other, swaps,
+    cycles, cells wanted by several movers (the shuffle decides) and -- in every fourth env -- two agents STARTING on one cell
+    (map_env.py:357-543 in full).  The ten-agent per-step kernels keep the pairwise loop's masks and "who stands on my target"
+    for the contested path and know from a bit in the env's header whether two agents may share a cell (set here by
+    ssd_set_state, afterwards by every step's consume phase); 60 steps, every step's observations and rewards and the final state
+    against the oracle, through per-call stepping, the rollout chains and the fused kernel."""
+    import torch
+    game = K.GAME_HARVEST if which == "harvest" else K.GAME_CLEANUP
+    amap = {"cleanup48x36": K.cleanup_map_48x36(), "cleanup25x18": K.CLEANUP_MAP, "harvest": K.HARVEST_MAP}[which]
+    E, N, steps = 160, 10, 60
+    eng = VecEngine(game, amap, num_envs=E, num_agents=N, seed=91)
+    ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), seed=91)
+    eng.reset()
+    ora.reset()
+    rng = np.random.RandomState(777)
+    st = ora.get_state()
+    fr = np.array([(r, c) for r in range(len(amap)) for c in range(len(amap[0])) if amap[r][c] != "@"])
+    pos, orient = st["pos"].copy(), st["orient"].copy()
+    for e in range(E):
+        if e % 5 == 4:
+            continue                                               # (these keep their spawn points)
+        anchor = fr[rng.randint(len(fr))]
+        near = np.argsort(np.abs(fr - anchor).sum(1) + 0.01 * rng.rand(len(fr)))[:N]
+        pos[e] = fr[near[rng.permutation(N)]]
+        if e % 4 == 1:
+            pos[e, rng.randint(1, N)] = pos[e, 0]                   # two agents on one cell
+        orient[e] = rng.randint(0, 4, size=N)
+    eng.set_state(pos=pos, orient=orient)
+    ora.set_state(pos=pos, orient=orient)
+    a_host = rng.randint(0, 5, size=(steps, E, N)).astype(np.int32)    # the four moves and STAY ...
+    other = rng.rand(steps, E, N) < 0.15
+    a_host[other] = rng.randint(5, 9 if game == K.GAME_CLEANUP else 8, size=int(other.sum()))   # ... and now and then a turn or a beam
+    a_dev = torch.from_numpy(a_host).cuda()
+    if mode == "calls":
+        for k in range(steps):
+            o, r, _ = eng.step(a_dev[k])
+            o_obs, o_rew, _ = ora.step(a_host[k])
+            np.testing.assert_array_equal(r.cpu().numpy(), o_rew, err_msg="rewards of step %d" % k)
+            assert np.array_equal(o.cpu().numpy(), o_obs), "observations of step %d differ" % k
+    else:
+        obs = torch.zeros((steps, E, N, 15, 15, 3), dtype=torch.uint8, device="cuda")
+        rew = torch.zeros((steps, E, N), dtype=torch.int32, device="cuda")
+        done = torch.zeros((steps, E, N), dtype=torch.uint8, device="cuda")
+        eng.set_rollout_chains(2 if mode == "chains" else 1)
+        eng.rollout_actions(a_dev, steps, obs, rew, done, reset_every=0, step0=0, fused=(mode == "fused"))
+        g_obs, g_rew = obs.cpu().numpy(), rew.cpu().numpy()
+        for k in range(steps):
+            o_obs, o_rew, _ = ora.step(a_host[k])
+            np.testing.assert_array_equal(g_rew[k], o_rew, err_msg="rewards of step %d" % k)
+            assert np.array_equal(g_obs[k], o_obs), "observations of step %d differ" % k
+    a, b = eng.get_state(), ora.get_state()
+    for key in ("world", "pos", "orient", "episode", "t"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert eng.status() == 0
+    eng.close()
+
+
 def test_per_call_steps_can_be_captured_into_a_hip_graph():
     """ssd_step with device pointers is ONE kernel launch on the caller's stream and nothing else -- no synchronisation, no
     allocation, no other stream -- so a training loop may capture it (with its policy) into a HIP graph: torch.cuda.CUDAGraph
