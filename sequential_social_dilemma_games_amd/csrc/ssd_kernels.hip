@@ -930,13 +930,12 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     clashm = ballot(is_agent & (nearest == 0u));
                     exact_loop = (clashm & M) != 0;              // a mover clashes: the slow path, with exact masks
                 }
-                // Ten agents (per-step kernels): a contested move is no longer rare (Cleanup 48 x 36: every launch has such waves in
-                // its tail), so the loop also keeps what the contested path would otherwise ask again with two more loops over the
-                // agents: the two masks apart, and -- per lane -- who stands on its target.
-#ifndef SSD_EXP_FOLD5       // (experiment switch: the five-agent kernels too)
-#define SSD_EXP_FOLD5 0
-#endif
-                constexpr bool kFold = !roll && (NA == 10 || (SSD_EXP_FOLD5 && NA == 5));
+                // The per-step kernels compiled for five or ten agents: the waves that take the contested path are their launch's tail
+                // (ten agents on Cleanup 48 x 36: 2.5 % of the envs, i.e. some in every launch), so the loop also keeps what that
+                // path would otherwise ask again with two more loops over the agents -- the two masks apart, and, per lane, who
+                // stands on its target: + 2 instructions per agent for every wave, - 150 and more for the tail.  Cleanup 48 x 36 with
+                // ten agents 7.05 -> 6.54 us per step, Harvest 5.18 -> 5.09, its 20-step call 6.41 -> 6.24 (alternating fresh processes).
+                constexpr bool kFold = !roll && NA > 0;
                 int occ_fold = -1;
                 if (exact_loop) {
                     // (a target that is not a mover's is a value no target equals: the loop then has no "is j a mover" test -- a
@@ -1012,7 +1011,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     all_apart = true;
 #endif
                 } else if (chains_only) {
-#ifdef SSD_EXP_MUT_CHAINS   // (mutation switch, wrong results: proves that the tests reach this path)
+#if defined(SSD_EXP_MUT_CHAINS) && SSD_EXP_MUT_CHAINS == 1   // (mutation switch, wrong results: proves that the tests reach this path)
                     if (mover) cell = tcell;
 #else
                     if (resolve_chains(mover & (tcell != cell), occ_fold)) cell = tcell;
@@ -1102,6 +1101,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                                 if constexpr (kFold) {           // (the list's first entry that is a contender)
                                     const uint64_t firstm = ballot(lane < nm && ((Cm >> (perm & 63u)) & 1ull) != 0);
                                     w = rl(perm, __builtin_ctzll(firstm));
+#if defined(SSD_EXP_MUT_CHAINS) && SSD_EXP_MUT_CHAINS == 2   // (mutation switch, wrong results: the lowest contender wins, not the shuffle's first)
+                                    w = (uint32_t)__builtin_ctzll(Cm);
+#endif
                                     // the agent that waited for the winner's cell finds it empty
                                     occ_fold = occ_fold == (int)w ? -1 : occ_fold;
                                     entered_taken |= Pm != 0;

@@ -663,17 +663,18 @@ def test_cleanup_steps_with_many_shooters(which, mode):
 
 @pytest.mark.parametrize("mode", ["calls", "chains", "fused"])
 @pytest.mark.parametrize("which", ["cleanup48x36", "cleanup25x18", "harvest"])
-def test_ten_agents_crowded_moves(which, mode):
-    """Ten agents that mostly MOVE, from crowded starts: targets that are taken, chains of agents following each other, swaps,
+@pytest.mark.parametrize("N", [10, 5])
+def test_crowded_moves(N, which, mode):
+    """Ten / five agents that mostly MOVE, from crowded starts: targets that are taken, chains of agents following each other, swaps,
     cycles, cells wanted by several movers (the shuffle decides) and -- in every fourth env -- two agents STARTING on one cell
-    (map_env.py:357-543 in full).  The ten-agent per-step kernels keep the pairwise loop's masks and "who stands on my target"
+    (map_env.py:357-543 in full).  The five- and ten-agent per-step kernels keep the pairwise loop's masks and "who stands on my target"
     for the contested path and know from a bit in the env's header whether two agents may share a cell (set here by
     ssd_set_state, afterwards by every step's consume phase); 60 steps, every step's observations and rewards and the final state
     against the oracle, through per-call stepping, the rollout chains and the fused kernel."""
     import torch
     game = K.GAME_HARVEST if which == "harvest" else K.GAME_CLEANUP
     amap = {"cleanup48x36": K.cleanup_map_48x36(), "cleanup25x18": K.CLEANUP_MAP, "harvest": K.HARVEST_MAP}[which]
-    E, N, steps = 160, 10, 60
+    E, steps = 160, 60
     eng = VecEngine(game, amap, num_envs=E, num_agents=N, seed=91)
     ora = pyoracle.Oracle(game, amap, E, N, G.default_lut(), seed=91)
     eng.reset()
