@@ -722,6 +722,36 @@ def test_crowded_moves(N, which, mode):
     eng.close()
 
 
+def test_agents_on_one_cell_survive_a_later_world_update():
+    """ssd_set_state(pos) tells the kernels that agents share a cell (a bit beside the header's waste counts); a later
+    ssd_set_state(world) -- which rewrites those counts for Cleanup -- must keep it: the steps that follow resolve the moves of the
+    overlapping agents as map_env.py:494-543 does, not as agents that stand apart."""
+    import torch
+    E, N, steps = 96, 5, 40
+    eng = VecEngine(K.GAME_CLEANUP, K.CLEANUP_MAP, num_envs=E, num_agents=N, seed=5)
+    ora = pyoracle.Oracle(K.GAME_CLEANUP, K.CLEANUP_MAP, E, N, G.default_lut(), seed=5)
+    eng.reset(); ora.reset()
+    st = ora.get_state()
+    pos = st["pos"].copy()
+    pos[:, 1] = pos[:, 0]                                           # agents 0 and 1 on one cell, everywhere
+    pos[::2, 3] = pos[::2, 2]                                       # ... and 2 and 3 in every other env
+    eng.set_state(pos=pos); ora.set_state(pos=pos)
+    world = ora.get_state()["world"].copy()
+    world[:, 2, 2] = np.where(world[:, 2, 2] == ord("H"), ord("R"), ord("H"))   # (a waste cell toggled: the call recounts the waste)
+    eng.set_state(world=world); ora.set_state(world=world)
+    rng = np.random.RandomState(11)
+    for k in range(steps):
+        a = rng.randint(0, 5, size=(E, N)).astype(np.int32)
+        o, r, _ = eng.step(torch.from_numpy(a).cuda())
+        o_obs, o_rew, _ = ora.step(a)
+        np.testing.assert_array_equal(r.cpu().numpy(), o_rew, err_msg="rewards of step %d" % k)
+        assert np.array_equal(o.cpu().numpy(), o_obs), "observations of step %d differ" % k
+    a, b = eng.get_state(), ora.get_state()
+    for key in ("world", "pos", "orient"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    eng.close()
+
+
 def test_per_call_steps_can_be_captured_into_a_hip_graph():
     """ssd_step with device pointers is ONE kernel launch on the caller's stream and nothing else -- no synchronisation, no
     allocation, no other stream -- so a training loop may capture it (with its policy) into a HIP graph: torch.cuda.CUDAGraph
