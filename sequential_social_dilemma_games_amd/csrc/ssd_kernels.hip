@@ -1549,8 +1549,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                         auto waste = [&](uint32_t ce, bool valid) {
                             ce = valid ? ce : safe;
                             const uint32_t c = ce & 0xFFFFu;                             // ties break on the cell: grid and dense order agree
+#ifdef SSD_EXP_WASTE_ONE_DRAW   // (experiment switch, results differ from the oracle's: one keyed draw per waste point instead of two)
+                            const uint32_t kh = draw(pk_ord, ce >> 16);
+                            const bool cand = valid & (s_world[c] != 'H') & ((uint64_t)kh < thr_w);
+#else
                             const bool cand = valid & (s_world[c] != 'H') & ((uint64_t)draw(pk_coin, ce >> 16) < thr_w);
                             const uint32_t kh = draw(pk_ord, ce >> 16);
+#endif
                             const bool better = cand & (!has | (kh < bh) | ((kh == bh) & (c < bl)));
                             bh = better ? kh : bh; bl = better ? c : bl; has = has | cand;
                         };
