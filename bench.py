@@ -246,9 +246,41 @@ def policy_step_leg(torch, game, amap, n_agents, E, steps=300, K=20):
             return (time.perf_counter() - t0) * 1e6 / n
         out["vector_env_step_us"] = per_call(lambda i: venv.step(acts[i % K]), steps)
         out["engine_step_us"] = per_call(lambda i: eng.step(acts[i % K], out=venv._out), steps)
+        calls = max(3, steps // K)
+        # (b') the same K per-call steps captured ONCE into a HIP graph (torch.cuda.CUDAGraph: ssd_step with device pointers is one
+        # kernel launch on the caller's stream and nothing else, tests/test_hip_parity.py) and replayed: what a training loop that
+        # captures policy + step gets -- the host's 5 - 6 us per hipLaunchKernel are gone, the kernels remain
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for k in range(K):
+                    eng.step(acts[k], out=venv._out)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for k in range(K):
+                    eng.step(acts[k], out=venv._out)
+            torch.cuda.synchronize()
+            for i in range(3):
+                graph.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(calls):
+                graph.replay()
+                torch.cuda.synchronize()
+            out["engine_step_hip_graph_k%d_us_per_step" % K] = (time.perf_counter() - t0) * 1e6 / (calls * K)
+            t0 = time.perf_counter()
+            for i in range(calls):
+                graph.replay()
+            torch.cuda.synchronize()
+            out["engine_step_hip_graph_back_to_back_us_per_step"] = (time.perf_counter() - t0) * 1e6 / (calls * K)
+            del graph
+        except Exception as exc:                     # (an optional figure: never the leg's failure)
+            out["engine_step_hip_graph_error"] = "%s: %s" % (type(exc).__name__, exc)
         ring = tuple(t.unsqueeze(0) for t in venv._out)
         eng.set_rollout_chains(0)
-        calls = max(3, steps // K)
 
         def chunk(i):
             eng.rollout_actions(acts, K, ring[0], ring[1], ring[2], reset_every=HORIZON, step0=(i * K) % HORIZON)

@@ -283,8 +283,10 @@ int run(ssd_env *env, int mode, const int32_t *actions, const uint8_t *order, co
         env->last_stream = s; env->last_stream_set = true;
         p.actions = actions; p.order = order; p.mask = mask; p.actions_out = actions_out;
         p.obs = obs; p.rew = rew; p.done = done;
-        // (measured: the per-call step with the coherent kernel variant -- nothing left dirty for the launch's release -- 7.9 against
-        // 8.0 us per Python call: back-to-back calls are bound by the host, tools/step_rate.py)
+        // (measured, round 2: the per-call step with the coherent kernel variant -- nothing left dirty for the launch's release -- 7.9
+        // against 8.0 us per Python call.  Round 4: twenty such steps captured into a HIP graph replay at the pace of twenty calls,
+        // 7.15 against 7.13 us per 4096-env step (bench.py, policy_step): back-to-back per-call steps are bound by the kernel --
+        // one launch whose waves step AND render, each launch waiting for the one before -- not by the host's 5 us per launch)
         ssd::launch(p, env->game, stream);
         SSD_HIP(env, hipGetLastError());
         return SSD_OK;
