@@ -537,7 +537,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // makes the 4096-env step SLOWER, 5.35 -> 5.53 us (Cleanup 5.79 -> 5.95; no difference at 1024 or 16 384 envs):
         // with two chains of launches in flight the step is not the wave's latency alone, and the staggered loads suit it.
         // Measured again at the end of round 3, on that round's kernels: 5.51 -> 5.66 us, Harvest 25 x 38 6.00 -> 6.18 -- a launch's
-        // loads are a burst the memory side serves at its own rate, and a wave that asks for everything at once lengthens it)
+        // loads are a burst the memory side serves at its own rate, and a wave that asks for everything at once lengthens it.
+        // And a third time on round 4's kernels, now behind a switch (-DSSD_EXP_HDR_LATE): Harvest 5.16 -> 5.40, Cleanup 5.48 -> 5.72,
+        // Harvest 25 x 38 5.81 -> 5.88, Cleanup 48 x 36 6.60 -> 6.58: profiles/r04_ab/hdr_late_r04.txt)
         // kPre (Cleanup, the map-specific coherent step kernels).  Cleanup's spawn pass starts with a DEPENDENT fetch: the two
         // thresholds of the current waste count (cleanup.py:156-171 through the host's tables), a scalar load that can only go
         // out once the beams have said how many cells they cleaned -- a round trip to L2 in the middle of the wave, with nothing
@@ -554,6 +556,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
         // wait -- the compiler is free to copy or reuse its destination register before the data lands.)
         constexpr bool kPre = GAME == 1 && MODE == kModeStep && COH && FAST != 0;
         uint4 hdr;
+        uint32_t hdr_lanes = 0;
         if (kCoh) {
             const uint32_t hv = cload(reinterpret_cast<const uint32_t *>(a_hdr + e) + (lane & 3));
             // (these kernel arguments are fetched while the header is on its way)
@@ -565,7 +568,11 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             if (GAME == 1) asm volatile("" ::"s"(p.waste_cells), "s"(n_waste), "s"(p.thr_ca), "s"(p.thr_cw), "s"(p.n_thr), "s"(p.rew), "s"(p.done), "s"(p.horizon));
             else asm volatile("" ::"s"(p.thr_h32[0]), "s"(p.thr_h32[1]), "s"(p.thr_h32[2]), "s"(p.thr_h32[3]), "s"(p.thr_h_always));
 #endif
+#ifndef SSD_EXP_HDR_LATE    // (experiment switch: the header's lanes read out after ALL the prologue's loads have been issued -- one round trip)
             hdr = make_uint4(rl(hv, 0), rl(hv, 1), rl(hv, 2), rl(hv, 3));
+#else
+            hdr_lanes = hv;
+#endif
         } else {
             hdr = a_hdr[e];
         }
@@ -635,6 +642,9 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             wlist[j] = 0u;
             if (GAME == 1 && 64 * j < n_waste) wlist[j] = (mode != kModeObserve && idx < n_waste) ? p.waste_cells[idx] : 0u;
         }
+#ifdef SSD_EXP_HDR_LATE
+        if (kCoh) hdr = make_uint4(rl(hdr_lanes, 0), rl(hdr_lanes, 1), rl(hdr_lanes, 2), rl(hdr_lanes, 3));
+#endif
         // kPre: thresholds by waste count, lane l holding those of (count in the header - l): the spawn pass will see the count
         // less what this step's CLEAN beams clean (cleanup.py:115 after :94-111), almost always within the window
         uint64_t thr_pa = 0, thr_pw = 0;
