@@ -473,8 +473,13 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
                     for (int j = 0; j < kGridLoads; ++j) g0[j] = load16_sc1(snap_r, (uint32_t)(lane * 16 + j * 1024));
                 }
 #pragma unroll
-                for (int j = 0; j < kGridLoads; ++j)
+                for (int j = 0; j < kGridLoads; ++j) {
+#ifdef SSD_EXP_RENDER_BLANK     // (experiment switch, wrong pictures: the grid is fetched as ever and then shown blank -- what of the no-fetch bound is the CONTENT's)
+                    asm volatile("" : "+v"(g0[j]));
+                    g0[j] = u32x4_t{0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
+#endif
                     if (lane * 16 + j * 1024 < S) *reinterpret_cast<uint4 *>(s_world + lane * 16 + j * 1024) = make_uint4(g0[j].x, g0[j].y, g0[j].z, g0[j].w);
+                }
                 wave_sync();
                 const uint32_t cellb = areg & 0xFFFFu, orientb = (areg >> 16) & 3u;
                 if (!snapshot) {
