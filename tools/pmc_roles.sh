@@ -8,7 +8,8 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/pmc_roles; mkdir -p $O
 python3 tools/_label.py "pmc_roles $TAG $*" > $O/$TAG.txt
-for PMC in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"; do
+# (PMC_LIST="SQ_WAVES SQ_INSTS_VALU ..." in the environment: other counters, at most eight SQ ones per pass; SQ_WAVES and SQ_INSTS_VALU tell the roles apart)
+for PMC in "${PMC_LIST:-SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD}"; do
   rm -rf $O/run
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $O/run -- python3 bench.py --steps 40 --warmup 8 --no-extras "$@" > $O/$TAG.log 2>&1
   echo "rc=$?"
@@ -36,7 +37,7 @@ for (name, waves), ds in sorted(groups.items()):
         w = sum(d["SQ_WAVES"] for d in part) / n
         print("%s  ~%d waves per launch, %d launches: per wave " % (name, waves, n) +
               "  ".join("%s %.1f" % (k.replace("SQ_INSTS_", ""), sum(d.get(k, 0) for d in part) / n / w)
-                        for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD")))
+                        for k in sorted(set().union(*[set(d) for d in part]) - {"name", "SQ_WAVES"})))
 PY
   rm -rf $O/run
 done
