@@ -639,6 +639,22 @@ def main():
                 holder["long_call_us_per_step"] = long_us
                 return wall * 1e6 - args.steps * long_us
             run_leg(holder, "call_overhead_us", overhead)
+
+            # ---- optional leg: the same K-step call once the process is warm.  The timed region above is the process's FIRST call of
+            #      its length, W steps (the driver's command: 5 steps = 30 us) after seconds of start-up with the device idle; a
+            #      training loop issues such calls back to back.  Median of 30 further calls of K steps, each synchronised.
+            def warm_calls():
+                walls = []
+                s0 = args.warmup + args.steps + 1000
+                for i in range(30):
+                    w, _, _ = time_rollout(torch, eng, ring, args.steps, 0, step0=s0 + i * args.steps)
+                    walls.append(w)
+                walls.sort()
+                med = walls[len(walls) // 2] * 1e6 / args.steps
+                return {"label": "NOT the headline: the same %d-step call, median of 30 issued back to back later in the same process" % args.steps,
+                        "us_per_step": med, "fastest_us_per_step": walls[0] * 1e6 / args.steps, "slowest_us_per_step": walls[-1] * 1e6 / args.steps,
+                        "roofline_frac": bytes_env * E / (med * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            run_leg(holder, "warm_process_call", warm_calls)
         # ---- optional leg: the same K steps from a stream that has work pending when the call comes (a rollout inside a training
         #      loop: policy kernels are still queued), so that the call forks from it -- the headline's region starts on an idle stream
         if plain:
