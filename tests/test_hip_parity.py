@@ -752,6 +752,36 @@ def test_agents_on_one_cell_survive_a_later_world_update():
     eng.close()
 
 
+def test_a_masked_reset_leaves_the_other_envs_shared_cells_alone():
+    """Agents that share a cell in EVERY env, then a reset of every other env (ssd_reset with a mask): the reset envs start from spawn
+    points of their own (their header says "apart" again), the others still hold their overlapping agents and keep resolving
+    their moves as map_env.py:494-543 does -- the bit a step's move phase trusts is per env."""
+    import torch
+    E, N, steps = 64, 5, 30
+    eng = VecEngine(K.GAME_HARVEST, K.HARVEST_MAP, num_envs=E, num_agents=N, seed=21)
+    ora = pyoracle.Oracle(K.GAME_HARVEST, K.HARVEST_MAP, E, N, G.default_lut(), seed=21)
+    eng.reset(); ora.reset()
+    pos = ora.get_state()["pos"].copy()
+    pos[:, 4] = pos[:, 3]
+    pos[:, 1] = pos[:, 0]
+    eng.set_state(pos=pos); ora.set_state(pos=pos)
+    mask = (np.arange(E) % 2).astype(np.uint8)
+    o = eng.reset(mask=torch.from_numpy(mask).cuda())
+    o_obs = ora.reset(mask=mask)
+    assert np.array_equal(o.cpu().numpy()[mask == 1], o_obs[mask == 1]), "observations of the reset envs differ"
+    rng = np.random.RandomState(3)
+    for k in range(steps):
+        a = rng.randint(0, 5, size=(E, N)).astype(np.int32)
+        o, r, _ = eng.step(torch.from_numpy(a).cuda())
+        o_obs, o_rew, _ = ora.step(a)
+        np.testing.assert_array_equal(r.cpu().numpy(), o_rew, err_msg="rewards of step %d" % k)
+        assert np.array_equal(o.cpu().numpy(), o_obs), "observations of step %d differ" % k
+    a, b = eng.get_state(), ora.get_state()
+    for key in ("world", "pos", "orient", "episode", "t"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    eng.close()
+
+
 def test_per_call_steps_can_be_captured_into_a_hip_graph():
     """ssd_step with device pointers is ONE kernel launch on the caller's stream and nothing else -- no synchronisation, no
     allocation, no other stream -- so a training loop may capture it (with its policy) into a HIP graph: torch.cuda.CUDAGraph
