@@ -287,6 +287,9 @@ __device__ __forceinline__ void render_views_std(const int lane, const int WP, c
     }
 }
 
+#ifndef SSD_ROLL_VKEYS      // (1: the rollout kernel hashes its phase keys on the vector unit, all streams at once)
+#define SSD_ROLL_VKEYS 1
+#endif
 // Per-phase cycle stamps for tools/phase_profile.py: compiled only into the diagnostic library
 // (make stamps); the product build contains no stamp code.
 #ifdef SSD_STAMPS
@@ -793,10 +796,14 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             aslot = aslot + 1 == (uint32_t)p.action_ring ? 0u : aslot + 1;
         };
         if constexpr (roll_acts) { aslot = (uint32_t)(p.step0 % p.action_ring); fetch_action(); }
+        // (rollout: the output slot's element offset as a running sum -- one 64-bit add per step instead of the 64-bit products of
+        // slot x envs x agents and of that x the observation bytes: the rollout kernel is short of scalar issue slots)
+        const size_t en_stride = (size_t)p.E_total * N;
+        size_t slot_en_run = roll ? (size_t)slot * en_stride : 0;
         for (;;) {
             const bool is_reset = (roll || auto_mode) ? in_reset : (mode == kModeReset);
             const bool is_step = (roll || auto_mode) ? !in_reset : (mode == kModeStep);
-            const size_t slot_en = roll ? (size_t)slot * (size_t)p.E_total * N : 0;     // element offset of the slot in rew / done
+            const size_t slot_en = roll ? slot_en_run : 0;   // element offset of the slot in rew / done (rollout: a running sum, below)
             if (roll || (auto_mode && in_reset)) {
                 // a fresh pass over the resident env: default priority, empty beam / occupancy layers, and on a reset
                 // the grid of reset_map() (:560-564) + custom_reset
@@ -853,7 +860,14 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             // needed stream reading its lane: 12 vector instructions instead of 12 scalar ones per stream.  A hash is three 32-bit
             // multiplies, quarter rate on the vector unit: with the pairwise test below on DPP as well, Harvest 5.13 -> 5.33 us per
             // step; the scalar form stays)
-            auto stream_key_of = [&](uint32_t stream) -> uint32_t { return stream_key(skey, stream); };
+            // (... and kept for the ROLLOUT kernel alone, like the pairwise test on DPP below: that kernel is bound by issue slots, the
+            // scalar unit's first -- 24 scalar instructions per Harvest step become 12 vector ones and two v_readlane)
+            uint32_t vkeys = 0;
+            if constexpr (roll && SSD_ROLL_VKEYS) vkeys = stream_key(skey, (uint32_t)lane);       // lane s: the key of stream s
+            auto stream_key_of = [&](uint32_t stream) -> uint32_t {
+                if constexpr (roll && SSD_ROLL_VKEYS) return rl(vkeys, stream);
+                else return stream_key(skey, stream);
+            };
             if (is_step) {
                 // ---- actions (map_env.py:171-173) ----
                 constexpr int kNumActions = GAME == 0 ? 8 : 9;   // harvest.py:44, cleanup.py:70
@@ -1868,6 +1882,7 @@ __global__ __launch_bounds__(64 * kMaxEnvsPerBlock) void ssd_env_kernel(uint4 *c
             if (in_reset) { in_reset = false; continue; }     // the step this reset was due before comes next
             if (++k_step >= p.n_steps) break;
             slot = slot + 1 == (uint32_t)p.ring ? 0u : slot + 1;
+            slot_en_run = slot == 0u ? 0 : slot_en_run + en_stride;
             if (to_reset >= 0) to_reset = (to_reset == 0 ? p.reset_every : to_reset) - 1;
             in_reset = to_reset == 0;
         }
